@@ -1,0 +1,38 @@
+"""Training loss (oracle; test infrastructure only).
+
+Restates `mixed_loss` (`tab_ddpm/gaussian_multinomial_diffsuion.py:636-675`) with
+the timestep, Gaussian noise and categorical uniforms injected (the reference
+draws them at `:639`, `:647`, `:651 -> :508-513`).
+"""
+import torch
+
+from . import gaussian, multinomial as mn
+from .network import mlp_diffusion
+
+
+def mixed_loss(tb, T, p, x, n_num, K, t, noise, uniforms, gaussian_loss_type="mse", dim_t=128):
+    """Returns (loss_multi.mean(), loss_gauss.mean()); differentiable w.r.t. tensors in `p`.
+
+    x [B, n_num + m] float32 with categories as float indices (`:641-642`).
+    """
+    has_cat = len(K) > 0 and int(K[0]) != 0
+    pt = torch.ones_like(t).float() / T                         # sample_time 'uniform' (:589-593)
+    x_num, x_cat = x[:, :n_num], x[:, n_num:]
+    x_num_t, log_cat_t = x_num, x_cat
+    if n_num > 0:
+        x_num_t = gaussian.q_sample(tb, x_num, t, noise)
+    if has_cat:
+        log_cat = mn.index_to_log_onehot(x_cat.long(), K)
+        idx_t = mn.sample_categorical(mn.q_pred(tb, log_cat, t, K), uniforms, K)
+        log_cat_t = mn.index_to_log_onehot(idx_t, K)
+    out = mlp_diffusion(p, torch.cat([x_num_t, log_cat_t], dim=1), t, dim_t)
+    out_num, out_cat = out[:, :n_num], out[:, n_num:]
+    loss_multi = torch.zeros((1,)).float()
+    loss_gauss = torch.zeros((1,)).float()
+    if has_cat:
+        loss_multi = mn.multinomial_loss(tb, out_cat, log_cat, log_cat_t, t, pt, K, T) / len(K)
+    if n_num > 0:
+        if gaussian_loss_type != "mse":
+            raise NotImplementedError("oracle restates the 'mse' branch every config uses")
+        loss_gauss = ((noise - out_num) ** 2).mean(dim=1)      # _gaussian_loss 'mse' (:287-288)
+    return loss_multi.mean(), loss_gauss.mean()

@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; the GPU box has neither
+the reference nor this need).  `tab_ddpm` is imported unmodified.  `Classifier`,
+the `cond_fn` closure, `Trainer` and `update_ema` live in modules whose top-level
+imports need packages absent from this image (icecream, faiss, ...), so their
+class/function definitions are compiled straight from the reference source text
+with `ast` and executed with the real `torch` / reference `timestep_embedding` in
+scope - no stand-in modules, no edited code, nothing copied into this repo.
+
+Every random draw the reference makes is recorded (torch RNG entry points are
+wrapped while the reference runs) and stored next to the outputs, so the HIP
+path and the oracle can be fed identical noise.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import ast
+import os
+import sys
+from collections import OrderedDict
+from copy import deepcopy
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from tab_ddpm.gaussian_multinomial_diffsuion import GaussianMultinomialDiffusion  # noqa: E402
+from tab_ddpm.modules import MLPDiffusion, timestep_embedding  # noqa: E402
+from tab_ddpm.utils import index_to_log_onehot  # noqa: E402
+from weights import classifier_shapes, mlp_shapes, seeded_state  # noqa: E402
+
+torch.set_num_threads(1)  # what `import lib` forces in the reference (lib/__init__.py:4)
+
+
+# --------------------------------------------------------------------------- helpers
+def _extract(path, name, inside=None):
+    """Return the ast node of class/function `name` (optionally nested in function `inside`)."""
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    scope = tree.body
+    if inside is not None:
+        scope = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == inside).body
+    return next(n for n in scope if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name == name)
+
+
+def _compile(node, ns, path):
+    mod = ast.Module(body=[node], type_ignores=[])
+    exec(compile(mod, os.path.join(REF, path), "exec"), ns)
+    return ns[node.name]
+
+
+def ref_classifier_cls():
+    ns = {"nn": nn, "torch": torch, "timestep_embedding": timestep_embedding}
+    return _compile(_extract("pipeline_utils.py", "Classifier"), ns, "pipeline_utils.py")
+
+
+def ref_cond_fn(classifier, classifier_scale):
+    ns = {"torch": torch, "F": F, "classifier": classifier, "classifier_scale": classifier_scale}
+    node = _extract("pipeline_utils.py", "cond_fn", inside="conditional_sampling_by_group_size")
+    return _compile(node, ns, "pipeline_utils.py")
+
+
+def ref_trainer_cls():
+    import pandas as pd
+    ns = {"torch": torch, "np": np, "pd": pd, "deepcopy": deepcopy}
+    _compile(_extract("scripts/utils_train.py", "update_ema"), ns, "scripts/utils_train.py")
+    return _compile(_extract("scripts/train.py", "Trainer"), ns, "scripts/train.py")
+
+
+class Tape:
+    """Record every tensor the torch RNG entry points hand to the reference."""
+    NAMES = ("randn", "randn_like", "rand_like", "randint", "multinomial")
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._orig = {n: getattr(torch, n) for n in self.NAMES}
+        for n, fn in self._orig.items():
+            setattr(torch, n, self._wrap(n, fn))
+        return self
+
+    def __exit__(self, *a):
+        for n, fn in self._orig.items():
+            setattr(torch, n, fn)
+
+    def _wrap(self, name, fn):
+        def w(*a, **k):
+            out = fn(*a, **k)
+            self.log.append((name, out.detach().clone()))
+            return out
+        return w
+
+    def take(self, name):
+        kind, v = self.log.pop(0)
+        assert kind == name, (kind, name)
+        return v
+
+
+def load_seeded(module, shapes, seed, scale=1.0):
+    st = seeded_state(shapes, seed, scale)
+    missing, unexpected = module.load_state_dict(st, strict=False)
+    assert not unexpected, unexpected
+    return st
+
+
+def P(st):
+    return {"p:" + k: v.detach().cpu().numpy() for k, v in st.items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def make_diffusion(K, n_num, net, T, sched="cosine"):
+    d = GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=T, scheduler=sched)
+    d.eval()
+    return d
+
+
+def make_mlp(d_in, d_layers, seed, scale=1.0):
+    net = MLPDiffusion(d_in, 0, "none", {"d_layers": list(d_layers), "dropout": 0.0})
+    st = load_seeded(net, mlp_shapes(d_in, d_layers), seed, scale)
+    net.eval()
+    return net, st
+
+
+# --------------------------------------------------------------------------- G1
+def g1_schedule():
+    out = {}
+    names = ["alphas", "log_alpha", "log_1_min_alpha", "log_1_min_cumprod_alpha", "log_cumprod_alpha",
+             "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+             "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+    for sched in ("cosine", "linear"):
+        for T in (50, 1000, 2000):
+            d = make_diffusion([0], 3, None, T, sched)
+            for n in names:
+                out[f"{sched}_{T}_{n}"] = getattr(d, n)
+            out[f"{sched}_{T}_posterior_variance_f64"] = d.posterior_variance
+            mv = torch.cat([d.posterior_variance[1].unsqueeze(0), (1. - d.alphas)[1:]], dim=0)  # as :209
+            out[f"{sched}_{T}_model_variance_f64"] = mv
+            out[f"{sched}_{T}_model_log_variance_f64"] = torch.log(mv)
+    save("g1_schedule.npz", **out)
+
+
+# --------------------------------------------------------------------------- G2
+def g2_mlp():
+    g = torch.Generator().manual_seed(2)
+    net, st = make_mlp(14, [64, 64], seed=21)
+    x = torch.randn(16, 14, generator=g)
+    t = torch.randint(0, 1000, (16,), generator=g)
+    with torch.no_grad():
+        out = net(x, t)
+    big, _ = make_mlp(15, [512, 1024, 1024, 1024, 1024, 512], seed=22)
+    xb = torch.randn(8, 15, generator=g)
+    tb = torch.randint(0, 1000, (8,), generator=g)
+    with torch.no_grad():
+        outb = big(xb, tb)
+        emb = timestep_embedding(t, 128)
+    save("g2_mlp.npz", x=x, t=t, out=out, temb=emb, big_x=xb, big_t=tb, big_out=outb, **P(st))
+
+
+# --------------------------------------------------------------------------- G3
+def g3_gauss_step():
+    T = 1000
+    d = make_diffusion([0], 6, None, T)
+    g = torch.Generator().manual_seed(3)
+    t = torch.tensor([999, 500, 1, 0] * 4)
+    B = len(t)
+    out = {"t": t}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        x = (2.0 * torch.randn(B, 6, generator=g, dtype=torch.float64)).to(dt)
+        eps = torch.randn(B, 6, generator=g)
+        grad = 0.3 * torch.randn(B, 6, generator=g)
+        for gtag, cf in (("plain", None), ("guided", lambda x_, t_, **kw: grad)):
+            torch.manual_seed(33)
+            with Tape() as tape:
+                r = d.gaussian_p_sample(eps, x, t, model_kwargs={}, cond_fn=cf)
+            out[f"{tag}_{gtag}_noise"] = tape.take("randn_like")
+            out[f"{tag}_{gtag}_sample"] = r["sample"]
+            out[f"{tag}_{gtag}_pred_xstart"] = r["pred_xstart"]
+        out[f"{tag}_x"], out[f"{tag}_eps"], out[f"{tag}_grad"] = x, eps, grad
+    x0 = torch.randn(B, 6, generator=g)
+    nz = torch.randn(B, 6, generator=g)
+    out["q_x0"], out["q_noise"], out["q_xt"] = x0, nz, d.gaussian_q_sample(x0, t, noise=nz)
+    save("g3_gauss_step.npz", **out)
+
+
+# --------------------------------------------------------------------------- G4
+def g4_multinomial_step():
+    T = 1000
+    g = torch.Generator().manual_seed(4)
+    out = {}
+    for tag, K in (("small", [3, 5, 2]), ("wide", [2, 7, 64, 65, 200, 1000, 33])):
+        d = make_diffusion(K, 0, None, T)
+        t = torch.tensor([999, 500, 1, 0] * 4)
+        B, S = len(t), int(sum(K))
+        logits = 3.0 * torch.randn(B, S, generator=g)
+        idx_t = torch.stack([torch.randint(0, k, (B,), generator=g) for k in K], dim=1)
+        idx_0 = torch.stack([torch.randint(0, k, (B,), generator=g) for k in K], dim=1)
+        log_xt = index_to_log_onehot(idx_t, d.num_classes)
+        log_x0 = index_to_log_onehot(idx_0, d.num_classes)
+        torch.manual_seed(44)
+        with Tape() as tape:
+            lp = d.p_pred(logits, log_xt, t, {})
+            new = d.log_sample_categorical(lp)
+        u = torch.cat([tape.take("rand_like") for _ in K], dim=1)
+        with Tape() as tape:
+            fwd = d.q_sample(log_x0, t)
+        uq = torch.cat([tape.take("rand_like") for _ in K], dim=1)
+        pt = torch.ones(B) / T
+        out.update({
+            f"{tag}_K": np.array(K), f"{tag}_t": t, f"{tag}_logits": logits, f"{tag}_idx_t": idx_t,
+            f"{tag}_idx_0": idx_0, f"{tag}_u": u, f"{tag}_log_model_prob": lp,
+            f"{tag}_idx_new": torch.stack([new[:, a:b].argmax(1) for a, b in
+                                           zip(d.offsets[:-1].tolist(), d.offsets[1:].tolist())], dim=1),
+            f"{tag}_uq": uq,
+            f"{tag}_idx_q": torch.stack([fwd[:, a:b].argmax(1) for a, b in
+                                         zip(d.offsets[:-1].tolist(), d.offsets[1:].tolist())], dim=1),
+            f"{tag}_Lt": d.compute_Lt(logits, log_x0, log_xt, t, {}),
+            f"{tag}_kl_prior": d.kl_prior(log_x0),
+            f"{tag}_vb": d._multinomial_loss(logits, log_x0, log_xt, t, pt, {}),
+        })
+    save("g4_multinomial_step.npz", **out)
+
+
+# --------------------------------------------------------------------------- G5
+def _tape_chain(tape, T, K, n_num, conditional):
+    has_cat = K[0] != 0
+    nz = {"z0": tape.take("randn")}
+    if has_cat and not conditional:
+        nz["u_init"] = torch.cat([tape.take("rand_like") for _ in K], dim=1)
+    if not conditional:
+        nz["y"] = tape.take("multinomial")
+    noise, us = [], []
+    for _ in range(T):
+        noise.append(tape.take("randn_like").double())
+        if has_cat:
+            us.append(torch.cat([tape.take("rand_like") for _ in K], dim=1))
+    nz["noise"] = torch.stack(noise)
+    if has_cat:
+        nz["u"] = torch.stack(us)
+    assert not tape.log
+    return nz
+
+
+def g5_chains():
+    T, B = 50, 64
+    K, n_num = [3, 5, 2], 4
+    net, st = make_mlp(n_num + sum(K), [64, 64], seed=51, scale=0.5)
+    d = make_diffusion(K, n_num, net, T)
+    torch.manual_seed(55)
+    with Tape() as tape:
+        x, _ = d.sample(B, torch.ones(1))
+    nz = _tape_chain(tape, T, K, n_num, conditional=False)
+    save("g5_chain_mixed.npz", K=np.array(K), n_num=n_num, T=T, sample=x, **{"nz:" + k: v for k, v in nz.items()}, **P(st))
+
+    n_num, C, hidden = 6, 7, [32, 64, 32]
+    net, st = make_mlp(n_num, [64, 64], seed=52, scale=0.5)
+    clf = ref_classifier_cls()(d_in=n_num, d_out=C, dim_t=128, hidden_sizes=hidden)
+    cst = load_seeded(clf, classifier_shapes(n_num, C, hidden), seed=53)
+    clf.eval()
+    d = make_diffusion([0], n_num, net, T)
+    ys = torch.randint(0, C, (B, 1), generator=torch.Generator().manual_seed(5))
+    cond_fn = ref_cond_fn(clf, 1.0)
+    torch.manual_seed(56)
+    with Tape() as tape:
+        x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cond_fn)
+    nz = _tape_chain(tape, T, [0], n_num, conditional=True)
+    save("g5_chain_cond.npz", n_num=n_num, T=T, C=C, hidden=np.array(hidden), ys=ys, sample=x,
+         **{"nz:" + k: v for k, v in nz.items()}, **P(st), **{"c:" + k: v.numpy() for k, v in cst.items()})
+
+
+# --------------------------------------------------------------------------- G6
+def g6_loss():
+    T, B = 1000, 32
+    g = torch.Generator().manual_seed(6)
+    out = {}
+    for tag, K, n_num in (("mixed", [3, 5, 2], 4), ("gauss", [0], 5)):
+        m = len(K) if K[0] else 0
+        net, st = make_mlp(n_num + (sum(K) if m else 0), [64, 64], seed=61)
+        net.train()
+        d = make_diffusion(K, n_num, net, T)
+        d.train()
+        cols = [torch.randn(B, n_num, generator=g)]
+        if m:
+            cols.append(torch.stack([torch.randint(0, k, (B,), generator=g) for k in K], dim=1).float())
+        x = torch.cat(cols, dim=1)
+        torch.manual_seed(66)
+        with Tape() as tape:
+            lm, lg = d.mixed_loss(x, {"y": torch.zeros(B, dtype=torch.long)})
+        (lm + lg).backward()
+        t = tape.take("randint")
+        noise = tape.take("randn_like")
+        out[f"{tag}_x"], out[f"{tag}_t"], out[f"{tag}_noise"] = x, t, noise
+        if m:
+            out[f"{tag}_u"] = torch.cat([tape.take("rand_like") for _ in K], dim=1)
+        assert not tape.log
+        out[f"{tag}_K"], out[f"{tag}_n_num"] = np.array(K), n_num
+        out[f"{tag}_loss_multi"], out[f"{tag}_loss_gauss"] = lm.detach(), lg.detach()
+        for k, v in net.named_parameters():
+            out[f"{tag}_p:{k}"] = v.detach()
+            out[f"{tag}_g:{k}"] = v.grad
+    save("g6_loss.npz", **out)
+
+
+# --------------------------------------------------------------------------- G7
+def g7_classifier():
+    g = torch.Generator().manual_seed(7)
+    Classifier = ref_classifier_cls()
+    out = {}
+    for tag, d_in, C, hidden, B, store in (("small", 6, 7, [32, 64, 32], 16, True),
+                                           ("real", 15, 25, [128, 256, 512, 1024, 512, 256, 128], 8, False)):
+        clf = Classifier(d_in=d_in, d_out=C, dim_t=128, hidden_sizes=hidden)
+        st = load_seeded(clf, classifier_shapes(d_in, C, hidden), seed=71)
+        clf.eval()
+        x = torch.randn(B, d_in, generator=g, dtype=torch.float64)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        y = torch.randint(0, C, (B, 1), generator=g)
+        with torch.no_grad():
+            logits = clf(x.float(), t)
+        grad = ref_cond_fn(clf, 1.5)(x, t, y=y)
+        out.update({f"{tag}_x": x, f"{tag}_t": t, f"{tag}_y": y, f"{tag}_logits": logits, f"{tag}_grad": grad,
+                    f"{tag}_hidden": np.array(hidden), f"{tag}_C": C})
+        if store:
+            out.update({f"{tag}_p:{k}": v for k, v in st.items()})
+    save("g7_classifier.npz", **out)
+
+
+# --------------------------------------------------------------------------- G8
+def g8_trainer():
+    T, B, steps = 1000, 32, 5
+    K, n_num = [3, 5, 2], 4
+    g = torch.Generator().manual_seed(8)
+    net, st = make_mlp(n_num + sum(K), [64, 64], seed=81)
+    net.train()
+    d = make_diffusion(K, n_num, net, T)
+    d.train()
+    batches = []
+    for _ in range(steps):
+        xb = torch.cat([torch.randn(B, n_num, generator=g),
+                        torch.stack([torch.randint(0, k, (B,), generator=g) for k in K], dim=1).float()], dim=1)
+        batches.append(xb)
+
+    def it():
+        for xb in batches:
+            yield xb.clone(), torch.zeros(B, dtype=torch.long)
+
+    tr = ref_trainer_cls()(d, it(), lr=6e-4, weight_decay=1e-5, steps=steps, device=torch.device("cpu"))
+    tr.log_every = 1
+    torch.manual_seed(88)
+    with Tape() as tape:
+        tr.run_loop()
+    out = {"K": np.array(K), "n_num": n_num, "T": T, "steps": steps, "lr": 6e-4, "wd": 1e-5,
+           "x": torch.stack(batches), "loss_history": tr.loss_history.to_numpy().astype(np.float64)}
+    ts, ns, us = [], [], []
+    for _ in range(steps):
+        ts.append(tape.take("randint"))
+        ns.append(tape.take("randn_like"))
+        us.append(torch.cat([tape.take("rand_like") for _ in K], dim=1))
+    assert not tape.log
+    out["t"], out["noise"], out["u"] = torch.stack(ts), torch.stack(ns), torch.stack(us)
+    out.update({"p0:" + k: v for k, v in st.items()})
+    out.update({"p1:" + k: v.detach() for k, v in net.named_parameters()})
+    out.update({"ema:" + k: v.detach() for k, v in tr.ema_model.named_parameters()})
+    save("g8_trainer.npz", **out)
+
+
+# --------------------------------------------------------------------------- G9
+def g9_gmm():
+    from sklearn.mixture import GaussianMixture
+    rng = np.random.RandomState(9)
+    N, k = 600, 6
+    num = rng.uniform(0, 1, (N, 5))
+    cat = np.eye(4)[rng.randint(0, 4, N)]
+    key = 0.01 * rng.uniform(0, 1, (N, 1))
+    X = np.concatenate([num + 0.3 * (rng.randint(0, 3, (N, 1))), 2.0 * cat, key], axis=1)
+    gmm = GaussianMixture(n_components=k, covariance_type="diag", init_params="k-means++", tol=1e-4, random_state=0)
+    gmm.fit(X)
+    lpn, lr = gmm._estimate_log_prob_resp(X)
+    save("g9_gmm.npz", X=X, weights=gmm.weights_, means=gmm.means_, precisions_chol=gmm.precisions_cholesky_,
+         log_prob_norm=lpn, log_resp=lr, labels=gmm.predict(X).astype(np.int64))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    fns = {"g1": g1_schedule, "g2": g2_mlp, "g3": g3_gauss_step, "g4": g4_multinomial_step, "g5": g5_chains,
+           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm}
+    for w in which:
+        fns[w]()

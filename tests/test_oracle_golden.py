@@ -1,0 +1,168 @@
+"""Pin the CPU oracle to the golden vectors captured from the reference (CPU only).
+
+Tolerances: the oracle runs the same torch-CPU ops as the reference, so most
+checks are exact; where op grouping differs (hand-written AdamW restatement,
+numpy vs torch float64 transcendentals) the bound is stated at the check.
+"""
+import numpy as np
+import torch
+
+import oracle
+from oracle import chain, gaussian, gmm, guidance, loss, multinomial as mn, network, schedule, trainer
+from conftest import golden, relerr, sub
+
+SCHED_KEYS = ["alphas", "log_alpha", "log_1_min_alpha", "log_1_min_cumprod_alpha", "log_cumprod_alpha",
+              "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+              "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+              "posterior_variance_f64", "model_variance_f64", "model_log_variance_f64"]
+
+
+def test_g1_schedule_tables():
+    g = golden("g1_schedule.npz")
+    for sched in ("cosine", "linear"):
+        for T in (50, 1000, 2000):
+            tb = schedule.tables(sched, T)
+            for k in SCHED_KEYS:
+                ref = g[f"{sched}_{T}_{k}"].numpy()
+                got = tb[k]
+                assert got.dtype == ref.dtype, (k, got.dtype, ref.dtype)
+                # float32 buffers are float64 values rounded once: allow 1 ulp for numpy-vs-torch log/exp
+                np.testing.assert_allclose(got, ref, rtol=1.2e-7 if ref.dtype == np.float32 else 1e-14,
+                                           atol=1e-38, err_msg=f"{sched} {T} {k}")
+
+
+def test_g2_mlp_forward():
+    g = golden("g2_mlp.npz")
+    p = sub(g, "p:")
+    assert torch.equal(network.timestep_embedding(g["t"], 128), g["temb"])
+    out = network.mlp_diffusion(p, g["x"], g["t"])
+    assert relerr(out, g["out"]) < 1e-6
+    from weights import mlp_shapes, seeded_state
+    pb = seeded_state(mlp_shapes(15, [512, 1024, 1024, 1024, 1024, 512]), 22)
+    assert relerr(network.mlp_diffusion(pb, g["big_x"], g["big_t"]), g["big_out"]) < 1e-6
+
+
+def test_g3_gaussian_step():
+    g = golden("g3_gauss_step.npz")
+    tb = schedule.tables("cosine", 1000)
+    t = g["t"]
+    for tag in ("f64", "f32"):
+        for gtag in ("plain", "guided"):
+            r = gaussian.p_sample(tb, g[f"{tag}_eps"], g[f"{tag}_x"], t, g[f"{tag}_{gtag}_noise"],
+                                  g[f"{tag}_grad"] if gtag == "guided" else None)
+            ref = g[f"{tag}_{gtag}_sample"]
+            assert r["sample"].dtype == ref.dtype == torch.float64
+            assert relerr(r["sample"], ref) < 1e-12
+            assert relerr(r["pred_xstart"], g[f"{tag}_{gtag}_pred_xstart"]) < 1e-12
+    assert torch.equal(gaussian.q_sample(tb, g["q_x0"], t, g["q_noise"]), g["q_xt"])
+
+
+def test_g4_multinomial_step():
+    g = golden("g4_multinomial_step.npz")
+    tb = schedule.tables("cosine", 1000)
+    for tag in ("small", "wide"):
+        K = g[f"{tag}_K"].tolist()
+        t = g[f"{tag}_t"]
+        new, lp = mn.p_sample(tb, g[f"{tag}_logits"], g[f"{tag}_idx_t"], t, g[f"{tag}_u"], K)
+        assert torch.equal(lp, g[f"{tag}_log_model_prob"])
+        assert torch.equal(new, g[f"{tag}_idx_new"])
+        assert torch.equal(mn.q_sample(tb, g[f"{tag}_idx_0"], t, g[f"{tag}_uq"], K), g[f"{tag}_idx_q"])
+        lx0 = mn.index_to_log_onehot(g[f"{tag}_idx_0"], K)
+        lxt = mn.index_to_log_onehot(g[f"{tag}_idx_t"], K)
+        assert torch.equal(mn.compute_Lt(tb, g[f"{tag}_logits"], lx0, lxt, t, K), g[f"{tag}_Lt"])
+        assert torch.equal(mn.kl_prior(tb, lx0, K, 1000), g[f"{tag}_kl_prior"])
+        pt = torch.ones(len(t)) / 1000
+        assert torch.equal(mn.multinomial_loss(tb, g[f"{tag}_logits"], lx0, lxt, t, pt, K, 1000), g[f"{tag}_vb"])
+
+
+def test_g5_chain_mixed():
+    g = golden("g5_chain_mixed.npz")
+    T, K, n_num = int(g["T"]), g["K"].tolist(), int(g["n_num"])
+    tb = schedule.tables("cosine", T)
+    x = chain.sample(tb, T, sub(g, "p:"), n_num, K, sub(g, "nz:"))
+    ref = g["sample"]
+    assert x.dtype == ref.dtype == torch.float64
+    assert torch.equal(x[:, n_num:], ref[:, n_num:])               # category indices: exact
+    assert relerr(x[:, :n_num], ref[:, :n_num]) < 1e-9
+
+
+def test_g5_chain_conditional():
+    g = golden("g5_chain_cond.npz")
+    T, n_num = int(g["T"]), int(g["n_num"])
+    tb = schedule.tables("cosine", T)
+    cp = sub(g, "c:")
+    ys = g["ys"]
+    grad_fn = lambda x, t: guidance.cond_grad(cp, x, t, ys, 1.0)
+    x = chain.conditional_sample(tb, T, sub(g, "p:"), n_num, grad_fn, sub(g, "nz:"))
+    assert relerr(x, g["sample"]) < 1e-9
+
+
+def test_g6_mixed_loss_and_grads():
+    g = golden("g6_loss.npz")
+    tb = schedule.tables("cosine", 1000)
+    for tag in ("mixed", "gauss"):
+        K, n_num = g[f"{tag}_K"].tolist(), int(g[f"{tag}_n_num"])
+        p = {k: v.clone().requires_grad_(True) for k, v in sub(g, f"{tag}_p:").items()}
+        lm, lg = loss.mixed_loss(tb, 1000, p, g[f"{tag}_x"], n_num, K, g[f"{tag}_t"], g[f"{tag}_noise"],
+                                 g.get(f"{tag}_u"))
+        assert torch.allclose(lm.detach(), g[f"{tag}_loss_multi"], rtol=1e-6, atol=0)
+        assert torch.allclose(lg.detach(), g[f"{tag}_loss_gauss"], rtol=1e-6, atol=0)
+        (lm + lg).backward()
+        for k, v in p.items():
+            assert relerr(v.grad, g[f"{tag}_g:{k}"]) < 1e-5, k
+
+
+def test_g7_classifier_and_cond_grad():
+    g = golden("g7_classifier.npz")
+    from weights import classifier_shapes, seeded_state
+    for tag in ("small", "real"):
+        if tag == "small":
+            p = sub(g, "small_p:")
+        else:
+            p = seeded_state(classifier_shapes(15, int(g["real_C"]), g["real_hidden"].tolist()), 71)
+        x, t, y = g[f"{tag}_x"], g[f"{tag}_t"], g[f"{tag}_y"]
+        with torch.no_grad():
+            assert relerr(guidance.classifier_logits(p, x.float(), t), g[f"{tag}_logits"]) < 1e-6
+        assert relerr(guidance.cond_grad(p, x, t, y, 1.5), g[f"{tag}_grad"]) < 1e-5
+
+
+def test_g8_trainer_trajectory():
+    g = golden("g8_trainer.npz")
+    T, K, n_num, steps = int(g["T"]), g["K"].tolist(), int(g["n_num"]), int(g["steps"])
+    tb = schedule.tables("cosine", T)
+    p = {k: v.clone() for k, v in sub(g, "p0:").items()}
+    draws = [{"t": g["t"][i], "noise": g["noise"][i], "u": g["u"][i]} for i in range(steps)]
+    hist, ema = trainer.run_loop(tb, T, p, list(g["x"]), draws, n_num, K, float(g["lr"]), float(g["wd"]), steps)
+    lh = g["loss_history"].numpy()          # rows: step, mloss, gloss, sum (rounded to 4 decimals, train.py:60-61)
+    for i, (lm, lg) in enumerate(hist):
+        assert abs(np.around(lm, 4) - lh[i, 1]) <= 1.01e-4 and abs(np.around(lg, 4) - lh[i, 2]) <= 1.01e-4
+    for k in p:
+        assert relerr(p[k].detach(), g["p1:" + k]) < 1e-5, k
+        assert relerr(ema[k], g["ema:" + k]) < 1e-6, k
+
+
+def test_adamw_restatement_matches_torch():
+    torch.manual_seed(0)
+    w = torch.randn(257)
+    w2 = w.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([w2], lr=6e-4, weight_decay=1e-5)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    for step in range(1, 6):
+        gr = torch.randn(257)
+        w2.grad = gr.clone()
+        opt.step()
+        trainer.adamw_reference_step(w, gr, m, v, step, 6e-4, 1e-5)
+        assert relerr(w, w2.detach()) < 1e-6
+
+
+def test_g9_gmm_estep():
+    g = golden("g9_gmm.npz")
+    lpn, lr, lab = gmm.estep(g["X"].numpy(), g["weights"].numpy(), g["means"].numpy(), g["precisions_chol"].numpy())
+    np.testing.assert_allclose(lpn, g["log_prob_norm"].numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lr, g["log_resp"].numpy(), rtol=1e-10, atol=1e-10)
+    assert np.array_equal(lab, g["labels"].numpy())          # cluster assignments: exact
+
+
+def test_oracle_header_says_test_only():
+    assert "TEST INFRASTRUCTURE ONLY" in oracle.__doc__
