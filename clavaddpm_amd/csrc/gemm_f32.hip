@@ -38,79 +38,114 @@ struct GemmArgs {
 };
 
 // ---- staging: global -> registers -> LDS ------------------------------------------------------------
-// K-major source S[rows, K] (ld): LDS image T[ROWS][BK+PAD].
-template <int ROWS, bool VEC>
-__device__ __forceinline__ void load_kmajor(f32x4 (&reg)[ROWS / 32], const float* __restrict__ S, int ld, int R,
-                                            int r0, int k0, int k_end, const float* __restrict__ sc,
-                                            const float* __restrict__ sh, int tid) {
+// All loads are branch-free: out-of-range slots read a clamped (valid) address and are zeroed by a select,
+// so the compiler can issue every load of a tile back to back and interleave them with the MFMAs.
+//
+// K-major source S[rows, K] (ld): LDS image T[ROWS][BK+PAD].  Slot s = tid + 256*i covers row s/8, k 4*(s%8)..+3.
+template <int ROWS>
+struct KMajorSrc {
+    const float* p[ROWS / 32];   // row base (clamped row)
+    bool rv[ROWS / 32];          // row in range
+    int kq;                      // this thread's k offset inside a tile
+    f32x4 s4, h4;                // A-prologue scale / shift of the tile in flight (AFF only)
+    __device__ __forceinline__ void init(const float* S, int ld, int R, int r0, int tid) {
+        kq = (tid & 7) << 2;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int s = tid + 256 * i;
-        const int row = r0 + (s >> 3);
-        const int k = k0 + ((s & 7) << 2);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < R) {
-            const float* p = S + (size_t)row * ld + k;
-            if (VEC && k + 3 < k_end) {
-                v = *reinterpret_cast<const f32x4*>(p);
-            } else {
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int row = r0 + ((tid + 256 * i) >> 3);
+            rv[i] = row < R;
+            p[i] = S + (size_t)min(row, R - 1) * ld;
+        }
+    }
+    // raw loads only (clamped addresses); validity and the affine prologue are applied in store(), so nothing
+    // consumes the loaded registers until the data is needed and the loads stay in flight behind the MFMAs
+    template <bool VEC, bool AFF>
+    __device__ __forceinline__ void load(f32x4 (&reg)[ROWS / 32], int k0, int k_end, const float* __restrict__ sc,
+                                         const float* __restrict__ sh) {
+        const int k = k0 + kq;
+        if (AFF) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + e < k_end) v[e] = p[e];
-            }
-            if (sc != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + e < k_end) v[e] = v[e] * sc[k + e] + sh[k + e];
+            for (int e = 0; e < 4; ++e) {
+                const int kk = min(k + e, k_end - 1);
+                s4[e] = sc[kk];
+                h4[e] = sh[kk];
             }
         }
-        reg[i] = v;
-    }
-}
-
-template <int ROWS>
-__device__ __forceinline__ void store_kmajor(float* T, const f32x4 (&reg)[ROWS / 32], int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int s = tid + 256 * i;
-        *reinterpret_cast<f32x4*>(T + (s >> 3) * (BK + PAD) + ((s & 7) << 2)) = reg[i];
-    }
-}
-
-// MN-major source S[K, rows] (ld): LDS image T[BK][ROWS+PAD].
-template <int ROWS, bool VEC>
-__device__ __forceinline__ void load_mnmajor(f32x4 (&reg)[ROWS / 32], const float* __restrict__ S, int ld, int R,
-                                             int r0, int k0, int k_end, int tid) {
-    constexpr int Q = ROWS / 4;  // float4 slots per k row
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int s = tid + 256 * i;
-        const int k = k0 + s / Q;
-        const int c = r0 + ((s % Q) << 2);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < k_end) {
-            const float* p = S + (size_t)k * ld + c;
-            if (VEC && c + 3 < R) {
-                v = *reinterpret_cast<const f32x4*>(p);
+        for (int i = 0; i < ROWS / 32; ++i) {
+            if (VEC) {   // K % 4 == 0: a float4 is entirely inside or entirely outside
+                reg[i] = *reinterpret_cast<const f32x4*>(p[i] + (k < k_end ? k : 0));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c + e < R) v[e] = p[e];
+                for (int e = 0; e < 4; ++e) reg[i][e] = p[i][k + e < k_end ? k + e : 0];
             }
         }
-        reg[i] = v;
     }
-}
-
-template <int ROWS>
-__device__ __forceinline__ void store_mnmajor(float* T, const f32x4 (&reg)[ROWS / 32], int tid) {
-    constexpr int Q = ROWS / 4;
+    template <bool AFF>
+    __device__ __forceinline__ void store(float* T, const f32x4 (&reg)[ROWS / 32], int k0, int k_end, int tid) const {
+        const int k = k0 + kq;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int s = tid + 256 * i;
-        *reinterpret_cast<f32x4*>(T + (s / Q) * (ROWS + PAD) + ((s % Q) << 2)) = reg[i];
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int s = tid + 256 * i;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = rv[i] && (k + e < k_end);
+                v[e] = ok ? (AFF ? reg[i][e] * s4[e] + h4[e] : reg[i][e]) : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(T + (s >> 3) * (BK + PAD) + ((s & 7) << 2)) = v;
+        }
     }
-}
+};
+
+// MN-major source S[K, rows] (ld): LDS image T[BK][ROWS+PAD].  Slot s covers k s/Q, columns 4*(s%Q)..+3.
+template <int ROWS>
+struct MNMajorSrc {
+    static constexpr int Q = ROWS / 4;
+    const float* S;
+    int ld, R;
+    int c[ROWS / 32], kk[ROWS / 32];
+    __device__ __forceinline__ void init(const float* S_, int ld_, int R_, int r0, int tid) {
+        S = S_; ld = ld_; R = R_;
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int s = tid + 256 * i;
+            kk[i] = s / Q;
+            c[i] = r0 + ((s % Q) << 2);
+        }
+    }
+    template <bool VEC, bool AFF>
+    __device__ __forceinline__ void load(f32x4 (&reg)[ROWS / 32], int k0, int k_end, const float*, const float*) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int k = k0 + kk[i];
+            const float* row = S + (size_t)(k < k_end ? k : 0) * ld;
+            if (VEC) {   // R % 4 == 0
+                reg[i] = *reinterpret_cast<const f32x4*>(row + (c[i] < R ? c[i] : 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) reg[i][e] = row[c[i] + e < R ? c[i] + e : 0];
+            }
+        }
+    }
+    template <bool AFF>
+    __device__ __forceinline__ void store(float* T, const f32x4 (&reg)[ROWS / 32], int k0, int k_end, int tid) const {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int s = tid + 256 * i;
+            const bool kok = k0 + kk[i] < k_end;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (kok && c[i] + e < R) ? reg[i][e] : 0.f;
+            *reinterpret_cast<f32x4*>(T + (s / Q) * (ROWS + PAD) + ((s % Q) << 2)) = v;
+        }
+    }
+};
+
+template <bool KMAJOR, int ROWS>
+struct SrcOf { using type = KMajorSrc<ROWS>; };
+template <int ROWS>
+struct SrcOf<false, ROWS> { using type = MNMajorSrc<ROWS>; };
 
 // ---- fragments: LDS -> one f32x4 per 32-row MFMA tile = the operand of 4 consecutive MFMAs -------------
 template <bool KMAJOR, int ROWS>
@@ -128,16 +163,43 @@ __device__ __forceinline__ f32x4 frag(const float* T, int row, int kc, int h) {
     }
 }
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case CLAVA_ACT_RELU: return v > 0.f ? v : 0.f;
-        case CLAVA_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
-        case CLAVA_ACT_SILU: return v / (1.f + expf(-v));
-        default: return v;
+// Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); the
+// per-register row offsets are compile-time, so their products with the leading dimensions stay scalar.
+template <int ACT, int TM, int TN>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const GemmArgs& g, float* C, int row_base,
+                                         int col_base) {
+    const GemmEpi& e = g.e;
+    const bool has_rowadd = e.rowadd != nullptr, has_mask = e.mask_src != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + j * 32;
+        const bool cok = col < g.N;
+        const int cc = min(col, g.N - 1);
+        const float bias = e.bias ? e.bias[cc] : 0.f;
+        const float cs = (e.col_scale ? e.col_scale[cc] : 1.f) * e.alpha;
+        float* Cp = C + (size_t)row_base * g.ldc + col;
+        const float* Rp = has_rowadd ? e.rowadd + (size_t)row_base * e.ldr + cc : nullptr;
+        const float* Mp = has_mask ? e.mask_src + (size_t)row_base * e.ldm + cc : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int ro = i * 32 + (reg & 3) + 8 * (reg >> 2);
+                const bool ok = cok && (row_base + ro < g.M);
+                float v = acc[i][j][reg] + bias;
+                if (has_rowadd) v += ok ? Rp[(size_t)ro * e.ldr] : 0.f;
+                if (ACT == CLAVA_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (ACT == CLAVA_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                else if (ACT == CLAVA_ACT_SILU) v = v / (1.f + expf(-v));
+                if (has_mask) v *= ((ok ? Mp[(size_t)ro * e.ldm] : 0.f) > 0.f ? 1.f : e.mask_slope);
+                v *= cs;
+                if (ok) Cp[(size_t)ro * g.ldc] = v;
+            }
+        }
     }
 }
 
-template <bool AK, bool BKM, int BM, int BN, bool VEC>
+template <bool AK, bool BKM, int BM, int BN, bool VEC, bool AFF>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
     constexpr int TM = BM / 64, TN = BN / 64;        // 32x32 MFMA tiles per wave, wave tile (BM/2)x(BN/2)
     constexpr int A_SZ = AK ? BM * (BK + PAD) : BK * (BM + PAD);
@@ -170,30 +232,29 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    typename SrcOf<AK, BM>::type srcA;
+    typename SrcOf<BKM, BN>::type srcB;
+    srcA.init(g.A, g.lda, g.M, m0, tid);
+    srcB.init(g.B, g.ldb, g.N, n0, tid);
     f32x4 ra[BM / 32], rb[BN / 32];
-    auto gload = [&](int kt) {
-        const int k0 = k_begin + kt * BK;
-        if (AK) load_kmajor<BM, VEC>(ra, g.A, g.lda, g.M, m0, k0, k_end, g.e.a_scale, g.e.a_shift, tid);
-        else load_mnmajor<BM, VEC>(ra, g.A, g.lda, g.M, m0, k0, k_end, tid);
-        if (BKM) load_kmajor<BN, VEC>(rb, g.B, g.ldb, g.N, n0, k0, k_end, nullptr, nullptr, tid);
-        else load_mnmajor<BN, VEC>(rb, g.B, g.ldb, g.N, n0, k0, k_end, tid);
-    };
-    auto sstore = [&](int buf) {
-        float* As = smem + buf * (A_SZ + B_SZ);
-        float* Bs = As + A_SZ;
-        if (AK) store_kmajor<BM>(As, ra, tid); else store_mnmajor<BM>(As, ra, tid);
-        if (BKM) store_kmajor<BN>(Bs, rb, tid); else store_mnmajor<BN>(Bs, rb, tid);
-    };
 
+    // Pipeline: registers hold tile kt+1 while tile kt is multiplied out of LDS buffer `cur`.  Half way through
+    // the tile the registers are written to the other LDS buffer (free since the barrier that ended tile kt-1)
+    // and the loads of tile kt+2 are issued, so both sit behind MFMAs; one barrier per tile.
     if (nk > 0) {
-        gload(0);
-        sstore(0);
+        srcA.template load<VEC, AFF>(ra, k_begin, k_end, g.e.a_scale, g.e.a_shift);
+        srcB.template load<VEC, false>(rb, k_begin, k_end, nullptr, nullptr);
+        srcA.template store<AFF>(smem, ra, k_begin, k_end, tid);
+        srcB.template store<false>(smem + A_SZ, rb, k_begin, k_end, tid);
+        if (nk > 1) {
+            srcA.template load<VEC, AFF>(ra, k_begin + BK, k_end, g.e.a_scale, g.e.a_shift);
+            srcB.template load<VEC, false>(rb, k_begin + BK, k_end, nullptr, nullptr);
+        }
     }
     __syncthreads();
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
         const float* As = smem + cur * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
 #pragma unroll
@@ -210,44 +271,42 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            if (kc == BK / 16 - 1 && kt + 1 < nk) {
+                float* An = smem + (cur ^ 1) * (A_SZ + B_SZ);
+                srcA.template store<AFF>(An, ra, k_begin + (kt + 1) * BK, k_end, tid);
+                srcB.template store<false>(An + A_SZ, rb, k_begin + (kt + 1) * BK, k_end, tid);
+                if (kt + 2 < nk) {
+                    srcA.template load<VEC, AFF>(ra, k_begin + (kt + 2) * BK, k_end, g.e.a_scale, g.e.a_shift);
+                    srcB.template load<VEC, false>(rb, k_begin + (kt + 2) * BK, k_end, nullptr, nullptr);
+                }
+            }
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const GemmEpi& e = g.e;
     float* C = g.C + (size_t)blockIdx.y * g.slab;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wc * (BN / 2) + j * 32 + r;
-        if (col >= g.N) continue;
-        const float bias = e.bias ? e.bias[col] : 0.f;
-        const float cs = e.col_scale ? e.col_scale[col] : 1.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = m0 + wr * (BM / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (row >= g.M) continue;
-                float v = acc[i][j][reg] + bias;
-                if (e.rowadd) v += e.rowadd[(size_t)row * e.ldr + col];
-                v = apply_act(v, e.act);
-                if (e.mask_src) v *= (e.mask_src[(size_t)row * e.ldm + col] > 0.f ? 1.f : e.mask_slope);
-                v *= cs;
-                v *= e.alpha;
-                C[(size_t)row * g.ldc + col] = v;
-            }
-        }
+    const int row_base = m0 + wr * (BM / 2) + 4 * h;
+    const int col_base = n0 + wc * (BN / 2) + r;
+    switch (g.e.act) {
+        case CLAVA_ACT_RELU: epilogue<CLAVA_ACT_RELU, TM, TN>(acc, g, C, row_base, col_base); break;
+        case CLAVA_ACT_LEAKY: epilogue<CLAVA_ACT_LEAKY, TM, TN>(acc, g, C, row_base, col_base); break;
+        case CLAVA_ACT_SILU: epilogue<CLAVA_ACT_SILU, TM, TN>(acc, g, C, row_base, col_base); break;
+        default: epilogue<CLAVA_ACT_NONE, TM, TN>(acc, g, C, row_base, col_base); break;
     }
 }
 
 template <bool AK, bool BKM, int BM, int BN>
 int launch_tiles(const GemmArgs& g, bool vec, int splitk, hipStream_t stream) {
     dim3 grid(g.tiles_m * g.tiles_n, splitk, 1);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, BM, BN, true>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, BM, BN, false>), grid, dim3(256), 0, stream, g);
+    const bool aff = g.e.a_scale != nullptr;
+    if (AK && BKM && aff) {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, BM, BN, true, AK && BKM>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, BM, BN, false, AK && BKM>), grid, dim3(256), 0, stream, g);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, BM, BN, true, false>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, BM, BN, false, false>), grid, dim3(256), 0, stream, g);
+    }
     CLAVA_CHECK_LAUNCH("clava_gemm_f32");
     return CLAVA_OK;
 }
@@ -285,7 +344,10 @@ int clava_launch_gemm_f32(const float* A, int lda, bool a_kmajor, const float* B
     g.k_per_split = (kps + BK - 1) / BK * BK;   // split boundaries stay multiples of BK (vector loads stay aligned)
     g.slab = slab;
     g.e = epi;
-    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    // vector (16-B) staging loads need aligned bases and leading dimensions, and extents that are multiples of 4
+    // along the contiguous axis of each operand (so a float4 is entirely inside or outside the matrix)
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                     ((a_kmajor ? K : M) % 4 == 0) && ((b_kmajor ? K : N) % 4 == 0);
     if (a_kmajor && b_kmajor) return launch_layout<true, true>(g, vec, splitk, stream);
     if (a_kmajor && !b_kmajor) return launch_layout<true, false>(g, vec, splitk, stream);
     if (!a_kmajor && !b_kmajor) return launch_layout<false, false>(g, vec, splitk, stream);
