@@ -18,7 +18,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libclava_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          f"-I{INCLUDE}", f"-I{HERE}"]
 
 

@@ -1,0 +1,290 @@
+// Layer-stack launchers (denoiser / classifier forward, classifier input gradient), the small guidance and
+// time-embedding kernels, and the host-side driver of a whole reverse-diffusion chain.  Everything is enqueued
+// on one stream; nothing synchronises with or copies to the host.
+#include "clava_hip.h"
+#include "step.h"
+
+namespace {
+
+// dlogits = onehot(y) - softmax(logits): one wavefront per row (C <= ~51 cluster classes, configs/*.json:11)
+__global__ void __launch_bounds__(256) logsoftmax_select_grad_kernel(const float* __restrict__ logits, int ld,
+                                                                     const int* __restrict__ y, float* __restrict__ d,
+                                                                     int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= B) return;
+    const float* l = logits + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, l[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sm = 0.f;
+    for (int c = lane; c < C; c += 64) sm += expf(l[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    const float lse = mx + logf(sm);
+    const int yy = y[row];
+    for (int c = lane; c < C; c += 64) d[(size_t)row * C + c] = (c == yy ? 1.f : 0.f) - expf(l[c] - lse);
+}
+
+__global__ void __launch_bounds__(256) timestep_embedding_kernel(const long long* __restrict__ t, int n,
+                                                                 const float* __restrict__ freqs, int half,
+                                                                 float* __restrict__ emb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * half) return;
+    const int r = i / half, k = i - r * half;
+    const float arg = (float)t[r] * freqs[k];
+    emb[(size_t)r * 2 * half + k] = cosf(arg);
+    emb[(size_t)r * 2 * half + half + k] = sinf(arg);
+}
+
+float act_slope(int act) { return act == CLAVA_ACT_LEAKY ? 0.01f : 0.f; }
+
+int check_net(const clava_net* net, const char* who) {
+    CLAVA_CHECK_ARG(net && net->n_layers > 0 && net->n_layers <= 64 && net->dims && net->w && net->b && net->act,
+                    "%s: incomplete clava_net", who);
+    for (int l = 0; l < net->n_layers; ++l) {
+        CLAVA_CHECK_ARG(net->dims[l] > 0 && net->dims[l + 1] > 0 && net->w[l], "%s: layer %d is empty", who, l);
+        CLAVA_CHECK_ARG(net->act[l] == CLAVA_ACT_NONE || net->act[l] == CLAVA_ACT_RELU || net->act[l] == CLAVA_ACT_LEAKY,
+                        "%s: layer %d: activation %d not supported in a stack", who, l, net->act[l]);
+    }
+    return CLAVA_OK;
+}
+
+const float* bn_of(const float* const* arr, int l) { return arr ? arr[l] : nullptr; }
+
+int net_forward(const clava_net* net, const float* x, int ldx, int M, const float* rowadd0, int ld_rowadd0,
+                float* const* outs, hipStream_t st) {
+    const float* in = x;
+    int ld = ldx;
+    for (int l = 0; l < net->n_layers; ++l) {
+        GemmEpi e = gemm_epi_plain();
+        e.bias = net->b[l];
+        e.act = net->act[l];
+        if (l == 0) { e.rowadd = rowadd0; e.ldr = ld_rowadd0; }
+        if (l > 0) { e.a_scale = bn_of(net->bn_scale, l - 1); e.a_shift = bn_of(net->bn_shift, l - 1); }
+        CLAVA_CHECK_ARG((e.a_scale == nullptr) == (e.a_shift == nullptr), "net_forward: bn_scale/bn_shift mismatch at layer %d", l);
+        int rc = clava_launch_gemm_f32(in, ld, true, net->w[l], net->dims[l], true, outs[l], net->dims[l + 1], M,
+                                       net->dims[l + 1], net->dims[l], e, 1, 0, st);
+        if (rc) return rc;
+        in = outs[l];
+        ld = net->dims[l + 1];
+    }
+    return CLAVA_OK;
+}
+
+int net_input_grad(const clava_net* net, int M, float* const* outs, const float* dlast, float* const* grads,
+                   float alpha, hipStream_t st) {
+    const float* g = dlast;   // d/d(output of layer l), layer n-1 has no activation above it
+    for (int l = net->n_layers - 1; l >= 0; --l) {
+        GemmEpi e = gemm_epi_plain();
+        if (l > 0) {          // fold the derivative of layer l-1's activation and BatchNorm into this product
+            if (net->act[l - 1] != CLAVA_ACT_NONE) {
+                e.mask_src = outs[l - 1];
+                e.ldm = net->dims[l];
+                e.mask_slope = act_slope(net->act[l - 1]);
+            }
+            e.col_scale = bn_of(net->bn_scale, l - 1);
+        } else {
+            e.alpha = alpha;
+        }
+        int rc = clava_launch_gemm_f32(g, net->dims[l + 1], true, net->w[l], net->dims[l], false, grads[l], net->dims[l],
+                                       M, net->dims[l], net->dims[l + 1], e, 1, 0, st);
+        if (rc) return rc;
+        g = grads[l];
+    }
+    return CLAVA_OK;
+}
+
+inline long long align64(long long v) { return (v + 63) / 64 * 64; }
+
+struct ChainWs {
+    float* x_in;        // [B, D_in] denoiser input
+    float* den[2];      // ping-pong hidden activations [B, max hidden width]
+    float* model_out;   // [B, D_in]
+    float* cls_out[64]; // classifier activations, all kept for the backward pass
+    float* cls_grad[2]; // ping-pong gradients [B, max width]
+    float* dlogits;     // [B, C]
+    float* gx;          // [B, n_num] guidance gradient
+    long long total;
+};
+
+int max_width(const clava_net* n, int from, int to) {
+    int w = 0;
+    for (int l = from; l <= to; ++l) w = n->dims[l] > w ? n->dims[l] : w;
+    return w;
+}
+
+void carve(const clava_chain* c, int B, float* base, ChainWs& w) {
+    long long off = 0;
+    auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += align64(n); return p; };
+    const clava_net* d = c->denoiser;
+    const int D = d->dims[0];
+    w.x_in = take((long long)B * D);
+    const int hw = max_width(d, 1, d->n_layers - 1);
+    w.den[0] = take((long long)B * hw);
+    w.den[1] = take((long long)B * hw);
+    w.model_out = take((long long)B * D);
+    w.dlogits = nullptr; w.gx = nullptr; w.cls_grad[0] = w.cls_grad[1] = nullptr;
+    if (c->classifier) {
+        const clava_net* k = c->classifier;
+        for (int l = 0; l < k->n_layers; ++l) w.cls_out[l] = take((long long)B * k->dims[l + 1]);
+        const int gw = max_width(k, 1, k->n_layers - 1);
+        w.cls_grad[0] = take((long long)B * gw);
+        w.cls_grad[1] = take((long long)B * gw);
+        w.dlogits = take((long long)B * k->dims[k->n_layers]);
+        w.gx = take((long long)B * c->n_num);
+    }
+    w.total = off;
+}
+
+int check_chain(const clava_chain* c, int B) {
+    CLAVA_CHECK_ARG(c && B > 0, "sample_chain: null descriptor or empty batch");
+    CLAVA_CHECK_ARG(c->sched.T > 0 && c->n_steps >= 0 && c->t_start < c->sched.T && c->t_start + 1 >= c->n_steps,
+                    "sample_chain: steps t_start=%d n_steps=%d do not fit T=%d", c->t_start, c->n_steps, c->sched.T);
+    int rc = check_net(c->denoiser, "sample_chain(denoiser)");
+    if (rc) return rc;
+    const clava_net* d = c->denoiser;
+    CLAVA_CHECK_ARG(d->n_layers >= 2, "sample_chain: denoiser needs proj + head at least");
+    CLAVA_CHECK_ARG(d->dims[0] == c->n_num + c->sumK && d->dims[d->n_layers] == c->n_num + c->sumK,
+                    "sample_chain: denoiser width %d/%d != n_num + sumK = %d", d->dims[0], d->dims[d->n_layers], c->n_num + c->sumK);
+    CLAVA_CHECK_ARG(c->denoiser_emb, "sample_chain: denoiser_emb table missing");
+    CLAVA_CHECK_ARG((c->m == 0) == (c->sumK == 0), "sample_chain: m / sumK mismatch");
+    CLAVA_CHECK_ARG(c->m == 0 || (c->offsets && c->log_k), "sample_chain: offsets / log_k missing");
+    if (c->classifier) {
+        rc = check_net(c->classifier, "sample_chain(classifier)");
+        if (rc) return rc;
+        CLAVA_CHECK_ARG(c->classifier->dims[0] == c->n_num, "sample_chain: classifier input width %d != n_num %d",
+                        c->classifier->dims[0], c->n_num);
+        CLAVA_CHECK_ARG(c->m == 0, "sample_chain: guidance is Gaussian-only (conditional_sample never carries categories)");
+        CLAVA_CHECK_ARG(c->classifier_emb && c->y, "sample_chain: classifier_emb / y missing");
+    }
+    return CLAVA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clava_logsoftmax_select_grad_f32(const float* logits, int ld, const int* y, float* dlogits, int B, int C,
+                                     void* stream) {
+    CLAVA_CHECK_ARG(logits && y && dlogits && B > 0 && C > 0 && ld >= C, "logsoftmax_select_grad: bad arguments");
+    hipLaunchKernelGGL(logsoftmax_select_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, y,
+                       dlogits, B, C);
+    CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_f32");
+    return CLAVA_OK;
+}
+
+int clava_timestep_embedding_f32(const long long* t, int n, const float* freqs, int dim, float* emb, void* stream) {
+    CLAVA_CHECK_ARG(t && freqs && emb && n > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad arguments (dim must be even)");
+    const int half = dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n * half + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, n,
+                       freqs, half, emb);
+    CLAVA_CHECK_LAUNCH("clava_timestep_embedding_f32");
+    return CLAVA_OK;
+}
+
+int clava_net_forward_f32(const clava_net* net, const float* x, int ldx, int M, const float* rowadd0, int ld_rowadd0,
+                          float* const* outs, void* stream) {
+    int rc = check_net(net, "net_forward");
+    if (rc) return rc;
+    CLAVA_CHECK_ARG(x && outs && M > 0 && ldx >= net->dims[0], "net_forward: bad arguments");
+    for (int l = 0; l < net->n_layers; ++l) CLAVA_CHECK_ARG(outs[l], "net_forward: outs[%d] is null", l);
+    return net_forward(net, x, ldx, M, rowadd0, ld_rowadd0, outs, (hipStream_t)stream);
+}
+
+int clava_net_input_grad_f32(const clava_net* net, int M, float* const* outs, const float* dlast, float* const* grads,
+                             float alpha, void* stream) {
+    int rc = check_net(net, "net_input_grad");
+    if (rc) return rc;
+    CLAVA_CHECK_ARG(outs && dlast && grads && M > 0, "net_input_grad: bad arguments");
+    for (int l = 0; l < net->n_layers; ++l) CLAVA_CHECK_ARG(grads[l] && outs[l], "net_input_grad: buffer %d is null", l);
+    return net_input_grad(net, M, outs, dlast, grads, alpha, (hipStream_t)stream);
+}
+
+long long clava_chain_workspace_floats(const clava_chain* c, int B) {
+    if (check_chain(c, B)) return -1;
+    ChainWs w;
+    carve(c, B, nullptr, w);
+    return w.total;
+}
+
+int clava_sample_chain_f32(const clava_chain* c, int B, double* x, int* idx, float* ws, long long ws_floats,
+                           void* stream) {
+    int rc = check_chain(c, B);
+    if (rc) return rc;
+    CLAVA_CHECK_ARG(x || c->n_num == 0, "sample_chain: x is null");
+    CLAVA_CHECK_ARG(idx || c->m == 0, "sample_chain: idx is null");
+    ChainWs w;
+    carve(c, B, ws, w);
+    CLAVA_CHECK_ARG(ws && ws_floats >= w.total, "sample_chain: workspace of %lld floats needed, %lld given", w.total, ws_floats);
+    hipStream_t st = (hipStream_t)stream;
+    const clava_net* d = c->denoiser;
+    const int D = d->dims[0], nd = d->n_layers;
+    const int emb_w = d->dims[1];
+
+    // denoiser input of the first step: float(x) | log-one-hot(idx)
+    rc = clava_launch_chain_input(x, idx, c->offsets, w.x_in, B, c->n_num, c->m, c->sumK, st);
+    if (rc) return rc;
+
+    for (int s = 0; s < c->n_steps; ++s) {
+        const int t = c->t_start - s;
+        const unsigned step_index = (unsigned)(c->sched.T - 1 - t);
+        // ---- denoiser forward: hidden activations ping-pong, only the head output is kept
+        float* outs[64];
+        for (int l = 0; l < nd - 1; ++l) outs[l] = w.den[l & 1];
+        outs[nd - 1] = w.model_out;
+        rc = net_forward(d, w.x_in, D, B, c->denoiser_emb + (size_t)t * emb_w, 0, outs, st);
+        if (rc) return rc;
+        // ---- guidance: grad_x log p(y | x_t)
+        const float* grad = nullptr;
+        if (c->classifier) {
+            const clava_net* k = c->classifier;
+            const int nk = k->n_layers, C = k->dims[nk];
+            rc = net_forward(k, w.x_in, D, B, c->classifier_emb + (size_t)t * k->dims[1], 0, w.cls_out, st);
+            if (rc) return rc;
+            rc = clava_logsoftmax_select_grad_f32(w.cls_out[nk - 1], C, c->y, w.dlogits, B, C, st);
+            if (rc) return rc;
+            float* grads[64];
+            for (int l = 1; l < nk; ++l) grads[l] = w.cls_grad[l & 1];
+            grads[0] = w.gx;
+            rc = net_input_grad(k, B, w.cls_out, w.dlogits, grads, c->guidance_scale, st);
+            if (rc) return rc;
+            grad = w.gx;
+        }
+        // ---- fused Gaussian step (writes float(x_next) straight into the next denoiser input)
+        if (c->n_num > 0) {
+            GaussStepArgs g;
+            g.s = c->sched; g.B = B; g.n_num = c->n_num;
+            g.eps = w.model_out; g.ld_eps = D;
+            g.x = x;
+            g.grad = grad; g.ld_grad = c->n_num;
+            g.noise = c->noise ? c->noise + (size_t)s * B * c->n_num : nullptr;
+            g.x_in = w.x_in; g.ld_xin = D;
+            g.pred_xstart = nullptr;
+            g.t_rows = nullptr; g.t = t;
+            g.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
+            g.seed = c->seed; g.row_offset = c->row_offset; g.step_index = step_index;
+            rc = clava_launch_gauss_step(g, st);
+            if (rc) return rc;
+        }
+        // ---- fused categorical step (writes the log-one-hot of the new indices into the next denoiser input)
+        if (c->m > 0) {
+            MultiStepArgs q;
+            q.s = c->sched; q.B = B; q.m = c->m; q.sumK = c->sumK; q.mode = MULTI_MODE_REVERSE;
+            q.logits = w.model_out + c->n_num; q.ld_logits = D;
+            q.idx_in = idx; q.idx_out = idx;
+            q.uniforms = c->uniforms ? c->uniforms + (size_t)s * B * c->sumK : nullptr; q.ld_u = c->sumK;
+            q.x_in = w.x_in + c->n_num; q.ld_xin = D;
+            q.log_prob = nullptr; q.ld_lp = 0;
+            q.offsets = c->offsets; q.log_k = c->log_k;
+            q.t_rows = nullptr; q.t = t;
+            q.seed = c->seed; q.row_offset = c->row_offset; q.step_index = step_index;
+            rc = clava_launch_multinomial_step(q, st);
+            if (rc) return rc;
+        }
+    }
+    return CLAVA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+// Fused per-step kernels of the reverse (and forward) diffusion.
+//
+// gauss_step_kernel       = gaussian_p_mean_variance + condition_mean + gaussian_p_sample
+//                           (tab_ddpm/gaussian_multinomial_diffsuion.py:200-237, 315-328, 354-383; ~25 ATen launches
+//                           and a device->host sync per step in the reference) in one pass over [B, n_num].
+// multinomial_step_kernel = predict_start + q_posterior + log_sample_categorical (+ index_to_log_onehot)
+//                           (:414-455, 506-516; tab_ddpm/utils.py:127-134), and the same machinery for the initial
+//                           draw (:1033-1035) and the forward q_sample (:518-523).  One wavefront owns one
+//                           (row, feature) block: lane-strided coalesced reads of the block's logits, wavefront
+//                           reductions for the two log-sum-exps and the Gumbel arg-max; per-feature offsets and
+//                           log K are staged in LDS.  The chain state is the category INDEX per feature, not the
+//                           [B, sum K] log-one-hot of the reference.
+//
+// Both are HBM-bound elementwise/reduction kernels.  Arithmetic follows the reference operation by operation,
+// including its dtype promotions (float64 chain state); the file is compiled with
+// -ffp-contract=off so that a*b + c*d rounds like the separate ATen ops do.
+#include "rng.h"
+#include "step.h"
+
+namespace {
+
+constexpr float LOG_TINY = -69.07755279541016f;   // log(float32(1e-30)): value of log(clamp(onehot, 1e-30)) off the hot class
+
+// ------------------------------------------------------------------------------------------------ Gaussian
+__global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
+    const long long n = (long long)a.B * a.n_num;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / a.n_num), col = (int)(i - (long long)row * a.n_num);
+        const int t = a.t_rows ? (int)a.t_rows[row] : a.t;
+        const float sr = a.s.sqrt_recip_alphas_cumprod[t], srm1 = a.s.sqrt_recipm1_alphas_cumprod[t];
+        const float c1 = a.s.posterior_mean_coef1[t], c2 = a.s.posterior_mean_coef2[t];
+        const float e = a.eps[(size_t)row * a.ld_eps + col];
+        const double xd = a.x[i];
+        double pred, mean;
+        if (a.x_is_f32) {          // first step of a chain: x is the float32 draw, the reference computes in float32 (:1029)
+            const float xf = (float)xd;
+            const float pf = sr * xf - srm1 * e;
+            pred = (double)pf;
+            mean = (double)(c1 * pf + c2 * xf);
+        } else {                   // afterwards x is float64; float32 tables promote, eps * table stays a float32 product (:305-306)
+            pred = (double)sr * xd - (double)(srm1 * e);
+            mean = (double)c1 * pred + (double)c2 * xd;
+        }
+        if (a.grad) {              // condition_mean: mean.float() + variance * gradient.float()  (:325-327)
+            const float g = a.grad[(size_t)row * a.ld_grad + col];
+            mean = (double)(float)mean + a.s.model_variance[t] * (double)g;
+        }
+        double z;
+        if (a.noise) {
+            z = a.noise[i];
+        } else {
+            const unsigned long long elem = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.n_num + col;
+            const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem, a.step_index, clava_rng::STREAM_GAUSS);
+            z = (double)clava_rng::to_normal(r.x, r.y);
+        }
+        const double keep = (t != 0) ? 1.0 : 0.0;              // nonzero_mask (:373-375)
+        const double out = mean + (keep * a.s.model_sigma[t]) * z;
+        a.x[i] = out;
+        if (a.pred_xstart) a.pred_xstart[i] = pred;
+        if (a.x_in) a.x_in[(size_t)row * a.ld_xin + col] = (float)out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ multinomial
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// log_add_exp (tab_ddpm/utils.py:104-106): one of the two exponentials is exp(0) = 1 exactly
+__device__ __forceinline__ float log_add_exp(float x, float y) {
+    const float m = fmaxf(x, y);
+    return m + logf(1.0f + expf(-fabsf(x - y)));
+}
+
+constexpr int CACHE = 16;            // classes per lane held in registers: blocks up to 64 * 16 = 1024 classes
+constexpr int MAX_LDS_FEATURES = 1024;
+
+struct BlockCtx {
+    const float* lg;     // logits of this (row, feature) block (REVERSE)
+    int K, hot, t, mode;
+    float mx, lsum;      // log-softmax statistics of the logits
+    float lca_p, l1mca_p, la_t, l1ma_t, logk;
+};
+
+// un-normalised log posterior of class c (REVERSE), or the q_pred log-probability (QSAMPLE), or 0 (INIT)
+__device__ __forceinline__ float unnormed(const BlockCtx& b, int c) {
+    if (b.mode == MULTI_MODE_INIT) return 0.f;
+    const float lx = (c == b.hot) ? 0.f : LOG_TINY;
+    if (b.mode == MULTI_MODE_QSAMPLE) return log_add_exp(lx + b.lca_p, b.l1mca_p - b.logk);          // q_pred at t (:403-412)
+    const float lp = (b.lg[c] - b.mx) - b.lsum;                                                       // predict_start (:414-424)
+    const float ev = (b.t == 0) ? lp : log_add_exp(lp + b.lca_p, b.l1mca_p - b.logk);                 // q_pred at t-1 (:436-443)
+    return ev + log_add_exp(lx + b.la_t, b.l1ma_t - b.logk);                                          // + q_pred_one_timestep (:449)
+}
+
+__global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) {
+    __shared__ int s_off[MAX_LDS_FEATURES + 1];
+    __shared__ float s_logk[MAX_LDS_FEATURES];
+    const bool staged = a.m <= MAX_LDS_FEATURES;
+    if (staged) {
+        for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
+        for (int i = threadIdx.x; i < a.m; i += blockDim.x) s_logk[i] = a.log_k[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long n_pairs = (long long)a.B * a.m;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long pair = wave0; pair < n_pairs; pair += n_waves) {
+        const int row = (int)(pair / a.m), f = (int)(pair - (long long)row * a.m);
+        const int o = staged ? s_off[f] : a.offsets[f];
+        BlockCtx b;
+        b.K = (staged ? s_off[f + 1] : a.offsets[f + 1]) - o;
+        b.logk = staged ? s_logk[f] : a.log_k[f];
+        b.mode = a.mode;
+        b.t = a.t_rows ? (int)a.t_rows[row] : a.t;
+        b.hot = (a.mode == MULTI_MODE_INIT) ? -1 : a.idx_in[(size_t)row * a.m + f];
+        b.lg = a.logits ? a.logits + (size_t)row * a.ld_logits + o : nullptr;
+        b.mx = 0.f; b.lsum = 0.f;
+        const int tp = (a.mode == MULTI_MODE_QSAMPLE) ? b.t : max(b.t - 1, 0);
+        b.lca_p = a.s.log_cumprod_alpha[tp];
+        b.l1mca_p = a.s.log_1_min_cumprod_alpha[tp];
+        b.la_t = a.s.log_alpha[b.t];
+        b.l1ma_t = a.s.log_1_min_alpha[b.t];
+
+        if (a.mode == MULTI_MODE_REVERSE) {       // log-softmax statistics of the block's logits
+            float mx = -INFINITY;
+            for (int c = lane; c < b.K; c += 64) mx = fmaxf(mx, b.lg[c]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+            for (int c = lane; c < b.K; c += 64) sm += expf(b.lg[c] - mx);
+            b.mx = mx;
+            b.lsum = logf(wave_sum(sm));
+        }
+
+        const bool cached = b.K <= 64 * CACHE;
+        float un[CACHE];
+        float lse = 0.f;
+        if (a.mode == MULTI_MODE_REVERSE) {       // normaliser of the posterior (sliced_logsumexp, utils.py:151-166)
+            float mx = -INFINITY;
+            if (cached) {
+#pragma unroll
+                for (int j = 0; j < CACHE; ++j) {
+                    const int c = lane + 64 * j;
+                    un[j] = (c < b.K) ? unnormed(b, c) : -INFINITY;
+                    mx = fmaxf(mx, un[j]);
+                }
+            } else {
+                for (int c = lane; c < b.K; c += 64) mx = fmaxf(mx, unnormed(b, c));
+            }
+            mx = wave_max(mx);
+            float sm = 0.f;
+            if (cached) {
+#pragma unroll
+                for (int j = 0; j < CACHE; ++j) sm += (lane + 64 * j < b.K) ? expf(un[j] - mx) : 0.f;
+            } else {
+                for (int c = lane; c < b.K; c += 64) sm += expf(unnormed(b, c) - mx);
+            }
+            lse = mx + logf(wave_sum(sm));
+        }
+
+        // Gumbel arg-max (log_sample_categorical, :506-516); ties resolve to the lowest class like torch.argmax
+        float best = -INFINITY;
+        int best_c = 0x7fffffff;
+        const unsigned long long elem0 = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.sumK + o;
+        auto visit = [&](int c, float u_n) {
+            const float lp = u_n - lse;
+            if (a.log_prob) a.log_prob[(size_t)row * a.ld_lp + o + c] = lp;
+            float u;
+            if (a.uniforms) {
+                u = a.uniforms[(size_t)row * a.ld_u + o + c];
+            } else {
+                const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem0 + c, a.step_index,
+                                                                 a.mode == MULTI_MODE_INIT ? clava_rng::STREAM_INIT_CAT : clava_rng::STREAM_CAT);
+                u = clava_rng::to_uniform(r.x);
+            }
+            const float g = -logf(-logf(u + 1e-30f) + 1e-30f);
+            const float sc = g + lp;
+            if (sc > best) { best = sc; best_c = c; }
+        };
+        if (cached && a.mode == MULTI_MODE_REVERSE) {
+#pragma unroll
+            for (int j = 0; j < CACHE; ++j) {
+                const int c = lane + 64 * j;
+                if (c < b.K) visit(c, un[j]);
+            }
+        } else {
+            for (int c = lane; c < b.K; c += 64) visit(c, unnormed(b, c));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oc = __shfl_xor(best_c, off, 64);
+            if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+        }
+        if (lane == 0) a.idx_out[(size_t)row * a.m + f] = best_c;
+        if (a.x_in) {                              // index_to_log_onehot for the next denoiser input (utils.py:127-134)
+            float* xo = a.x_in + (size_t)row * a.ld_xin + o;
+            for (int c = lane; c < b.K; c += 64) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
+        }
+    }
+}
+
+// forward noising of the numeric columns, per-row t (gaussian_q_sample, :172-180)
+__global__ void __launch_bounds__(256) gauss_qsample_kernel(ScheduleDev s, int B, int n, const float* __restrict__ x0,
+                                                            const float* __restrict__ noise, const long long* __restrict__ t,
+                                                            float* __restrict__ out, int ld_out) {
+    const long long total = (long long)B * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / n), col = (int)(i - (long long)row * n);
+        const int tt = (int)t[row];
+        out[(size_t)row * ld_out + col] = s.sqrt_alphas_cumprod[tt] * x0[i] + s.sqrt_one_minus_alphas_cumprod[tt] * noise[i];
+    }
+}
+
+// x_T ~ N(0, I): float32 normal draws (the reference draws torch.randn in float32, :1029) stored in the float64 state
+__global__ void __launch_bounds__(256) gauss_init_kernel(double* __restrict__ x, int B, int n, unsigned long long seed,
+                                                         unsigned long long row_offset) {
+    const long long total = (long long)B * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long elem = row_offset * (unsigned long long)n + (unsigned long long)i;
+        const clava_rng::u4 r = clava_rng::philox4x32_10(seed, elem, 0u, clava_rng::STREAM_INIT_GAUSS);
+        x[i] = (double)clava_rng::to_normal(r.x, r.y);
+    }
+}
+
+__global__ void __launch_bounds__(256) chain_input_kernel(const double* __restrict__ x, const int* __restrict__ idx,
+                                                         const int* __restrict__ offsets, float* __restrict__ x_in, int B,
+                                                         int n_num, int m, int sumK) {
+    const int D = n_num + sumK;
+    const long long n = (long long)B * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / D), col = (int)(i - (long long)row * D);
+        float v;
+        if (col < n_num) {
+            v = (float)x[(size_t)row * n_num + col];
+        } else {
+            const int c = col - n_num;
+            int lo = 0, hi = m;              // feature f with offsets[f] <= c < offsets[f+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (offsets[mid] <= c) lo = mid; else hi = mid;
+            }
+            v = (idx[(size_t)row * m + lo] == c - offsets[lo]) ? 0.f : LOG_TINY;
+        }
+        x_in[i] = v;
+    }
+}
+
+}  // namespace
+
+int clava_launch_chain_input(const double* x, const int* idx, const int* offsets, float* x_in, int B, int n_num, int m,
+                             int sumK, hipStream_t stream) {
+    const long long n = (long long)B * (n_num + sumK);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(chain_input_kernel, dim3(grid), dim3(256), 0, stream, x, idx, offsets, x_in, B, n_num, m, sumK);
+    CLAVA_CHECK_LAUNCH("clava_chain_input");
+    return CLAVA_OK;
+}
+
+int clava_launch_gauss_step(const GaussStepArgs& a, hipStream_t stream) {
+    CLAVA_CHECK_ARG(a.B > 0 && a.n_num > 0, "gauss_step: empty shape");
+    CLAVA_CHECK_ARG(a.eps && a.x, "gauss_step: null eps/x");
+    CLAVA_CHECK_ARG(a.t_rows || (a.t >= 0 && a.t < a.s.T), "gauss_step: t=%d outside [0,%d)", a.t, a.s.T);
+    const long long n = (long long)a.B * a.n_num;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gauss_step_kernel, dim3(grid), dim3(256), 0, stream, a);
+    CLAVA_CHECK_LAUNCH("clava_gauss_step");
+    return CLAVA_OK;
+}
+
+int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
+    CLAVA_CHECK_ARG(a.B > 0 && a.m > 0 && a.sumK > 0, "multinomial_step: empty shape");
+    CLAVA_CHECK_ARG(a.idx_out && a.offsets && a.log_k, "multinomial_step: null idx_out/offsets/log_k");
+    CLAVA_CHECK_ARG(a.mode == MULTI_MODE_INIT || a.idx_in, "multinomial_step: idx_in required");
+    CLAVA_CHECK_ARG(a.mode != MULTI_MODE_REVERSE || a.logits, "multinomial_step: logits required");
+    CLAVA_CHECK_ARG(a.t_rows || (a.t >= 0 && a.t < a.s.T), "multinomial_step: t=%d outside [0,%d)", a.t, a.s.T);
+    const long long pairs = (long long)a.B * a.m;
+    const long long blocks = (pairs + 3) / 4;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(multinomial_step_kernel, dim3(grid), dim3(256), 0, stream, a);
+    CLAVA_CHECK_LAUNCH("clava_multinomial_step");
+    return CLAVA_OK;
+}
+
+extern "C" {
+
+int clava_gauss_step_f32(const clava_schedule* sched, int B, int n_num, const float* eps, int ld_eps, double* x,
+                         const float* grad, int ld_grad, const double* noise, float* x_in, int ld_xin,
+                         double* pred_xstart, const long long* t_rows, int t, int x_is_f32, unsigned long long seed,
+                         unsigned long long row_offset, unsigned step_index, void* stream) {
+    CLAVA_CHECK_ARG(sched, "gauss_step: null schedule");
+    GaussStepArgs a;
+    a.s = *sched; a.B = B; a.n_num = n_num;
+    a.eps = eps; a.ld_eps = ld_eps; a.x = x; a.grad = grad; a.ld_grad = ld_grad; a.noise = noise;
+    a.x_in = x_in; a.ld_xin = ld_xin; a.pred_xstart = pred_xstart; a.t_rows = t_rows; a.t = t; a.x_is_f32 = x_is_f32;
+    a.seed = seed; a.row_offset = row_offset; a.step_index = step_index;
+    return clava_launch_gauss_step(a, (hipStream_t)stream);
+}
+
+int clava_multinomial_step_f32(const clava_schedule* sched, int mode, int B, int m, int sumK, const int* offsets,
+                               const float* log_k, const float* logits, int ld_logits, const int* idx_in,
+                               int* idx_out, const float* uniforms, int ld_u, float* x_in, int ld_xin,
+                               float* log_prob, int ld_lp, const long long* t_rows, int t, unsigned long long seed,
+                               unsigned long long row_offset, unsigned step_index, void* stream) {
+    CLAVA_CHECK_ARG(sched, "multinomial_step: null schedule");
+    CLAVA_CHECK_ARG(mode >= MULTI_MODE_REVERSE && mode <= MULTI_MODE_QSAMPLE, "multinomial_step: unknown mode %d", mode);
+    MultiStepArgs a;
+    a.s = *sched; a.B = B; a.m = m; a.sumK = sumK; a.mode = mode;
+    a.logits = logits; a.ld_logits = ld_logits; a.idx_in = idx_in; a.idx_out = idx_out;
+    a.uniforms = uniforms; a.ld_u = ld_u; a.x_in = x_in; a.ld_xin = ld_xin; a.log_prob = log_prob; a.ld_lp = ld_lp;
+    a.offsets = offsets; a.log_k = log_k; a.t_rows = t_rows; a.t = t;
+    a.seed = seed; a.row_offset = row_offset; a.step_index = step_index;
+    return clava_launch_multinomial_step(a, (hipStream_t)stream);
+}
+
+int clava_gauss_qsample_f32(const clava_schedule* sched, int B, int n_num, const float* x0, const float* noise,
+                            const long long* t_rows, float* x_t, int ld_xt, void* stream) {
+    CLAVA_CHECK_ARG(sched && x0 && noise && t_rows && x_t && B > 0 && n_num > 0 && ld_xt >= n_num, "gauss_qsample: bad arguments");
+    const long long n = (long long)B * n_num;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gauss_qsample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *sched, B, n_num, x0, noise, t_rows,
+                       x_t, ld_xt);
+    CLAVA_CHECK_LAUNCH("clava_gauss_qsample_f32");
+    return CLAVA_OK;
+}
+
+int clava_gauss_init_f64(double* x, int B, int n_num, unsigned long long seed, unsigned long long row_offset, void* stream) {
+    CLAVA_CHECK_ARG(x && B > 0 && n_num > 0, "gauss_init: bad arguments");
+    const long long n = (long long)B * n_num;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gauss_init_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, B, n_num, seed, row_offset);
+    CLAVA_CHECK_LAUNCH("clava_gauss_init_f64");
+    return CLAVA_OK;
+}
+
+}  // extern "C"

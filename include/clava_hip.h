@@ -58,6 +58,133 @@ int clava_gemm_dgrad_f32(const float* dy, int lddy, const float* w, int ldw, con
 int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, float* dw_slabs, int lddw, int M,
                          int N_out, int K_in, int splits, void* stream);
 
+/* ---- schedule tables ---------------------------------------------------------------------------------------
+ * Device-resident tables of length T, built by the host exactly as GaussianMultinomialDiffusion.__init__ builds
+ * them (tab_ddpm/gaussian_multinomial_diffsuion.py:105-156); model_variance is the "fixed-large" variance the
+ * reference rebuilds every step at :209-211 and model_sigma = exp(0.5*log(model_variance)) (:382), both float64. */
+typedef struct clava_schedule {
+    int T;
+    const float* sqrt_recip_alphas_cumprod;
+    const float* sqrt_recipm1_alphas_cumprod;
+    const float* posterior_mean_coef1;
+    const float* posterior_mean_coef2;
+    const double* model_variance;
+    const double* model_sigma;
+    const float* log_alpha;
+    const float* log_1_min_alpha;
+    const float* log_cumprod_alpha;
+    const float* log_1_min_cumprod_alpha;
+    const float* sqrt_alphas_cumprod;
+    const float* sqrt_one_minus_alphas_cumprod;
+} clava_schedule;
+
+/* ---- fused diffusion steps ---------------------------------------------------------------------------------
+ * One Gaussian reverse step on x[B,n_num] (float64 chain state, updated in place):
+ *   x <- mean(eps, x, t) [+ variance_t * grad] + 1[t != 0] * sigma_t * z
+ * Replaces gaussian_p_mean_variance + condition_mean + gaussian_p_sample (:200-237, :315-328, :354-383).
+ * eps = numeric columns of the denoiser output (float32, leading dimension ld_eps); grad = cond_fn output or NULL;
+ * noise = injected z [B,n_num] float64, or NULL for the counter-based generator keyed by
+ * (seed, step_index, row_offset + row, column); t_rows = per-row timesteps (int64) or NULL to use `t` for every
+ * row; x_is_f32 != 0 reproduces the float32 arithmetic of a chain's first step (x is then the float32 draw of
+ * :1029).  x_in (optional) receives float(x_next) for the next denoiser call; pred_xstart is optional. */
+int clava_gauss_step_f32(const clava_schedule* sched, int B, int n_num, const float* eps, int ld_eps, double* x,
+                         const float* grad, int ld_grad, const double* noise, float* x_in, int ld_xin,
+                         double* pred_xstart, const long long* t_rows, int t, int x_is_f32, unsigned long long seed,
+                         unsigned long long row_offset, unsigned step_index, void* stream);
+
+/* One categorical step on index state idx[B,m] (m features, feature f owns classes offsets[f]..offsets[f+1]).
+ *   mode 0 (reverse): idx_out ~ p(x_{t-1} | x_t = idx_in, logits)   = p_sample (:468-472): predict_start (:414-424),
+ *                     q_posterior (:426-455), log_sample_categorical (:506-516)
+ *   mode 1 (init):    idx_out ~ uniform categorical                  = the initial draw of `sample` (:1033-1035)
+ *   mode 2 (q_sample):idx_out ~ q(x_t | x_0 = idx_in)                = q_sample (:518-523)
+ * uniforms = injected U[0,1) draws [B,sumK] (feature blocks side by side, the reference's draw order) or NULL for
+ * the counter-based generator.  x_in (optional) receives the log-one-hot of idx_out (index_to_log_onehot,
+ * tab_ddpm/utils.py:127-134); log_prob (optional, mode 0) receives the normalised log p(x_{t-1}|x_t) of p_pred
+ * (:457-466).  log_k[f] = log(float(K_f)) in float32.  idx_in may alias idx_out. */
+int clava_multinomial_step_f32(const clava_schedule* sched, int mode, int B, int m, int sumK, const int* offsets,
+                               const float* log_k, const float* logits, int ld_logits, const int* idx_in,
+                               int* idx_out, const float* uniforms, int ld_u, float* x_in, int ld_xin,
+                               float* log_prob, int ld_lp, const long long* t_rows, int t, unsigned long long seed,
+                               unsigned long long row_offset, unsigned step_index, void* stream);
+
+/* x_t[B,n_num] = sqrt_alphas_cumprod[t] * x0 + sqrt_one_minus_alphas_cumprod[t] * noise, per-row t (int64):
+ * gaussian_q_sample (:172-180), float32. */
+int clava_gauss_qsample_f32(const clava_schedule* sched, int B, int n_num, const float* x0, const float* noise,
+                            const long long* t_rows, float* x_t, int ld_xt, void* stream);
+
+/* x[B,n_num] (float64) <- standard normal draws, generated in float32 like torch.randn of :1029 / :990, from the
+ * counter-based generator keyed by (seed, row_offset + row, column). */
+int clava_gauss_init_f64(double* x, int B, int n_num, unsigned long long seed, unsigned long long row_offset,
+                         void* stream);
+
+/* ---- layer stacks --------------------------------------------------------------------------------------------
+ * A stack of Linear layers: layer l maps dims[l] -> dims[l+1] with weight w[l] ([dims[l+1], dims[l]], row-major),
+ * bias b[l], activation act[l]; bn_scale[l]/bn_shift[l] (entries or the arrays themselves may be NULL) are an
+ * eval-mode BatchNorm1d applied to layer l's activated output.  All arrays are HOST arrays; w/b/bn_* entries are
+ * device pointers.  MLPDiffusion (tab_ddpm/modules.py:425-460) = proj, 6 ReLU blocks, head; Classifier
+ * (pipeline_utils.py:584-630) = proj, Linear+ReLU+BN, 6 x Linear+LeakyReLU+BN, Linear. */
+typedef struct clava_net {
+    int n_layers;
+    const int* dims;
+    const float* const* w;
+    const float* const* b;
+    const int* act;
+    const float* const* bn_scale;
+    const float* const* bn_shift;
+} clava_net;
+
+/* outs[l] (host array of device pointers) receives layer l's activated, pre-BatchNorm output [M, dims[l+1]].
+ * rowadd0 is added to layer 0's pre-activation (the time embedding of `proj(x) + emb`, modules.py:459;
+ * pipeline_utils.py:627); ld_rowadd0 == 0 broadcasts one row.  Replaces MLPDiffusion.forward / Classifier.forward. */
+int clava_net_forward_f32(const clava_net* net, const float* x, int ldx, int M, const float* rowadd0, int ld_rowadd0,
+                          float* const* outs, void* stream);
+
+/* Input gradient of the stack: given the forward's `outs` and dlast = d(loss)/d(last output) [M, dims[n_layers]],
+ * computes grads[l] = d(loss)/d(pre-activation of layer l-1) for l = n_layers-1..1 and grads[0] = alpha *
+ * d(loss)/d(x) [M, dims[0]] (grads = host array of n_layers device pointers, grads[l] is [M, dims[l]]).
+ * Replaces the torch.autograd.grad call of cond_fn (pipeline_utils.py:864) below the log-softmax. */
+int clava_net_input_grad_f32(const clava_net* net, int M, float* const* outs, const float* dlast,
+                             float* const* grads, float alpha, void* stream);
+
+/* dlogits[b,c] = 1[c == y[b]] - softmax(logits[b,:])[c]: gradient of sum_b log_softmax(logits)[b, y_b]
+ * (cond_fn, pipeline_utils.py:862-864). */
+int clava_logsoftmax_select_grad_f32(const float* logits, int ld, const int* y, float* dlogits, int B, int C,
+                                     void* stream);
+
+/* emb[i, 0:dim] = [cos(t_i * freqs), sin(t_i * freqs)] (timestep_embedding, tab_ddpm/modules.py:20-38);
+ * freqs [dim/2] float32 is computed by the host (exp in float32 as torch does); t is int64; dim must be even. */
+int clava_timestep_embedding_f32(const long long* t, int n, const float* freqs, int dim, float* emb, void* stream);
+
+/* ---- whole reverse chain -----------------------------------------------------------------------------------
+ * Runs n_steps reverse steps t = t_start, t_start-1, ... on B rows: denoiser forward, optional classifier guidance
+ * (forward + log-softmax-select + input gradient), fused Gaussian step, fused categorical step.  Replaces the
+ * loop body of `sample` (:1043-1062) and `conditional_sample` (:995-1014).  Nothing is copied to the host. */
+typedef struct clava_chain {
+    clava_schedule sched;
+    int t_start;                 /* first timestep to process (T-1 for a fresh chain) */
+    int n_steps;                 /* number of steps t = t_start, t_start-1, ... to run (T for a full chain) */
+    int n_num, m, sumK;          /* numeric columns, categorical features, total classes (0, 0 when none) */
+    const int* offsets;          /* device [m+1] */
+    const float* log_k;          /* device [m] */
+    const clava_net* denoiser;   /* dims[0] == n_num + sumK == dims[n_layers] */
+    const float* denoiser_emb;   /* device [T, dims[1]]: time_embed(timestep_embedding(t)) for every t */
+    const clava_net* classifier; /* NULL for unguided sampling; dims[0] == n_num */
+    const float* classifier_emb; /* device [T, dims[1]] */
+    const int* y;                /* device [B] cluster label per row (guidance target) */
+    float guidance_scale;        /* classifier_scale (pipeline_utils.py:864) */
+    unsigned long long seed, row_offset;
+    const double* noise;         /* device [n_steps, B, n_num] injected Gaussian noise, or NULL */
+    const float* uniforms;       /* device [n_steps, B, sumK] injected uniforms, or NULL */
+    int first_step_f32;          /* x holds float32 values on entry (fresh chain) */
+} clava_chain;
+
+/* number of floats of workspace clava_sample_chain_f32 needs for B rows */
+long long clava_chain_workspace_floats(const clava_chain* c, int B);
+
+/* x [B,n_num] float64 (in: x at t_start, out: x after n_steps steps), idx [B,m] int32 likewise; ws = device workspace. */
+int clava_sample_chain_f32(const clava_chain* c, int B, double* x, int* idx, float* ws, long long ws_floats,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

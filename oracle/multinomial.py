@@ -82,6 +82,23 @@ def q_posterior(tb, log_x0, log_xt, t, K):
     return u - sliced_logsumexp(u, K)
 
 
+def sliced_logsumexp_exact(x, K):
+    """Per-block log-sum-exp evaluated directly in float64 (no row-wide scan).  NOT what the reference computes:
+    its `sliced_logsumexp` subtracts two row-wide float32 logcumsumexp values, which cancels catastrophically for
+    blocks that sit behind a lot of earlier probability mass (errors up to ~4e-2 on the 1371-class fixture, and
+    different on every platform).  Used only to check the HIP kernel's normaliser, which is a direct per-block
+    reduction as well."""
+    off = offsets(K)
+    cols = [torch.logsumexp(x[:, off[f]:off[f + 1]].double(), dim=1, keepdim=True).expand(-1, int(K[f])) for f in range(len(K))]
+    return torch.cat(cols, dim=1)
+
+
+def p_pred_exact_norm(tb, model_out, log_xt, t, K):
+    """`p_pred` with the exact normaliser (see `sliced_logsumexp_exact`); float64."""
+    u = q_posterior_unnormed(tb, predict_start(model_out, K), log_xt, t, K)
+    return u.double() - sliced_logsumexp_exact(u, K)
+
+
 def p_pred(tb, model_out, log_xt, t, K):
     """`p_pred` (`:457-466`), 'x0' parametrisation."""
     return q_posterior(tb, predict_start(model_out, K), log_xt, t, K)

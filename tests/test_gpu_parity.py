@@ -1,0 +1,128 @@
+"""GPU parity of the HIP path against the golden vectors captured from the reference, through the C ABI.
+
+Tolerances (north_star): category indices and cluster labels exact; numeric columns within 1e-4 relative
+(float32 GEMMs differ from the CPU sgemm by summation order only, ~1e-7 per layer).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import golden, relerr, sub
+from weights import classifier_shapes, mlp_shapes, seeded_state
+
+from clavaddpm_amd.pipeline_utils import Classifier, make_cond_fn
+from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion, timestep_embedding
+
+DEV = "cuda"
+
+
+def make_mlp(d_in, d_layers, state):
+    net = MLPDiffusion(d_in, 0, "none", {"d_layers": list(d_layers), "dropout": 0.0})
+    net.load_state_dict(state)
+    return net.to(DEV).eval()
+
+
+def make_diffusion(K, n_num, net, T, sched="cosine"):
+    return GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=T, scheduler=sched, device=torch.device(DEV)).to(DEV).eval()
+
+
+def test_g2_mlp_forward():
+    g = golden("g2_mlp.npz")
+    temb = timestep_embedding(g["t"].to(DEV), 128).cpu()
+    # the reference's float32 exp() for the frequencies is 1-ulp accurate and CPU-dependent; a 1-ulp frequency
+    # difference moves cos/sin(t * f) by up to t * 2^-24 ~ 6e-5 at t ~ 1000 (see modules._freqs)
+    assert float((temb - g["temb"]).abs().max()) < 1e-4
+    with torch.no_grad():
+        out = make_mlp(14, [64, 64], sub(g, "p:"))(g["x"].to(DEV), g["t"].to(DEV)).cpu()
+        assert relerr(out, g["out"]) < 1e-5
+        big = make_mlp(15, [512, 1024, 1024, 1024, 1024, 512], seeded_state(mlp_shapes(15, [512, 1024, 1024, 1024, 1024, 512]), 22))
+        assert relerr(big(g["big_x"].to(DEV), g["big_t"].to(DEV)).cpu(), g["big_out"]) < 1e-5
+
+
+def test_g3_gaussian_step():
+    g = golden("g3_gauss_step.npz")
+    d = make_diffusion([0], 6, None, 1000)
+    t = g["t"].to(DEV)
+    for tag in ("f64", "f32"):
+        for gtag in ("plain", "guided"):
+            grad = g[f"{tag}_grad"].to(DEV)
+            cf = (lambda x, t_, **kw: grad) if gtag == "guided" else None
+            r = d.gaussian_p_sample(g[f"{tag}_eps"].to(DEV), g[f"{tag}_x"].to(DEV), t, model_kwargs={}, cond_fn=cf,
+                                    noise=g[f"{tag}_{gtag}_noise"])
+            assert r["sample"].dtype == torch.float64
+            assert relerr(r["sample"].cpu(), g[f"{tag}_{gtag}_sample"]) < 1e-12, (tag, gtag)
+            assert relerr(r["pred_xstart"].cpu(), g[f"{tag}_{gtag}_pred_xstart"]) < 1e-12, (tag, gtag)
+    xt = d.gaussian_q_sample(g["q_x0"].to(DEV), t, noise=g["q_noise"].to(DEV)).cpu()
+    assert torch.equal(xt, g["q_xt"])
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_g4_multinomial_step(tag):
+    g = golden("g4_multinomial_step.npz")
+    K = g[f"{tag}_K"].tolist()
+    d = make_diffusion(K, 0, None, 1000)
+    t = g[f"{tag}_t"].to(DEV)
+    new, lp = d.p_sample_index(g[f"{tag}_logits"].to(DEV), g[f"{tag}_idx_t"].to(DEV), t, g[f"{tag}_u"], return_log_prob=True)
+    assert torch.equal(new.cpu().long(), g[f"{tag}_idx_new"])                    # sampled category indices: exact
+    # log p(x_{t-1} | x_t): the reference normaliser is a difference of two row-wide float32 logcumsumexp values
+    # (tab_ddpm/utils.py:151-166) and cancels catastrophically on wide rows (up to 4e-2 off on this 1371-class
+    # fixture, platform-dependent); the kernel reduces each block directly.  So: against the golden values where the
+    # cancellation is benign (10 classes), and against the oracle with an exact float64 normaliser everywhere.
+    if tag == "small":
+        assert float((lp.cpu() - g[f"{tag}_log_model_prob"]).abs().max()) < 5e-5
+    from oracle import multinomial as mn, schedule
+    tb = schedule.tables("cosine", 1000)
+    exact = mn.p_pred_exact_norm(tb, g[f"{tag}_logits"], mn.index_to_log_onehot(g[f"{tag}_idx_t"], K), g[f"{tag}_t"], K)
+    assert float((lp.cpu().double() - exact).abs().max()) < 2e-5
+    q = d.q_sample_index(g[f"{tag}_idx_0"].to(DEV), t, g[f"{tag}_uq"])
+    assert torch.equal(q.cpu().long(), g[f"{tag}_idx_q"])
+
+
+def test_g5_chain_mixed():
+    g = golden("g5_chain_mixed.npz")
+    T, K, n_num = int(g["T"]), g["K"].tolist(), int(g["n_num"])
+    net = make_mlp(n_num + sum(K), [64, 64], sub(g, "p:"))
+    d = make_diffusion(K, n_num, net, T)
+    x, out = d.sample(64, torch.ones(1), noise=sub(g, "nz:"))
+    ref = g["sample"]
+    assert x.dtype == torch.float64 and x.shape == ref.shape and not x.is_cuda
+    assert torch.equal(x[:, n_num:], ref[:, n_num:])                              # category indices: exact
+    assert relerr(x[:, :n_num], ref[:, :n_num]) < 1e-4
+    assert torch.equal(out["y"].cpu(), g["nz:y"])
+
+
+def _classifier(g, prefix, d_in, C, hidden):
+    clf = Classifier(d_in=d_in, d_out=C, dim_t=128, hidden_sizes=hidden)
+    clf.load_state_dict(sub(g, prefix) if prefix else seeded_state(classifier_shapes(d_in, C, hidden), 71))
+    return clf.to(DEV).eval()
+
+
+def test_g5_chain_conditional():
+    g = golden("g5_chain_cond.npz")
+    T, n_num, C = int(g["T"]), int(g["n_num"]), int(g["C"])
+    net = make_mlp(n_num, [64, 64], sub(g, "p:"))
+    d = make_diffusion([0], n_num, net, T)
+    clf = _classifier(g, "c:", n_num, C, g["hidden"].tolist())
+    ys = g["ys"]
+    x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1.0), noise=sub(g, "nz:"))
+    assert relerr(x, g["sample"]) < 1e-4
+    # the same chain with the guidance supplied as an opaque Python callback (the reference's closure contract)
+    fused = make_cond_fn(clf, 1.0)
+    x2, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys.to(DEV)}, cond_fn=lambda x_, t_, y=None: fused(x_, t_, y=y),
+                                 noise=sub(g, "nz:"))
+    assert relerr(x2, g["sample"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["small", "real"])
+def test_g7_classifier_and_cond_grad(tag):
+    g = golden("g7_classifier.npz")
+    hidden, C = g[f"{tag}_hidden"].tolist(), int(g[f"{tag}_C"])
+    x, t, y = g[f"{tag}_x"].to(DEV), g[f"{tag}_t"].to(DEV), g[f"{tag}_y"].to(DEV)
+    clf = _classifier(g, "small_p:" if tag == "small" else None, x.shape[1], C, hidden)
+    with torch.no_grad():
+        assert relerr(clf(x.float(), t).cpu(), g[f"{tag}_logits"]) < 1e-5
+    grad = make_cond_fn(clf, 1.5)(x, t, y=y)
+    assert grad.dtype == torch.float32
+    assert relerr(grad.cpu(), g[f"{tag}_grad"]) < 1e-4
