@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: synthetic rows/sec of 1000-step cluster-guided reverse diffusion on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]                     (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY section 8d "M2"): the movie_lens (movie -> rating) relation, the
+largest child table of that config: D_in = n_num = 2 (rating + the sibling relation's cluster column), C = 50
+cluster classes, denoiser MLP [512,1024,1024,1024,1024,512], classifier [128,256,512,1024,512,256,128],
+sampling batch 20000 rows, classifier_scale 1.0, T = 1000 reverse steps (configs/movie_lens.json; BASELINE.md
+section 2).  Weights are PyTorch default init under seed 0, cluster labels uniform - throughput does not depend on
+trained values.  One "step" = one full T-step chain over one 20000-row batch on every rank (rows are sharded per
+GPU, no collective on the data path: weak scaling).
+
+The JSON line also carries
+  roofline     - the dominant kernel (fp32 MFMA GEMM, 128x128 tile, NT layout): algorithmic FLOPs per launch over
+                 its mean launch duration, both from HIP events recorded on the launch stream inside the timed
+                 region (clava_prof_*), against the 157.3 TFLOP/s dense fp32 matrix peak of MI355X;
+  cpu_baseline - the CPU oracle (a torch-CPU restatement of the reference path, pinned to the reference's golden
+                 vectors) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+DENOISER_LAYERS = [512, 1024, 1024, 1024, 1024, 512]
+CLASSIFIER_LAYERS = [128, 256, 512, 1024, 512, 256, 128]
+
+
+def build_workload(device, n_num, n_clusters, T):
+    import numpy as np
+    from clavaddpm_amd.pipeline_utils import Classifier, make_cond_fn
+    from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+    torch.manual_seed(0)
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(DENOISER_LAYERS), "dropout": 0.0}).to(device).eval()
+    clf = Classifier(d_in=n_num, d_out=n_clusters, dim_t=128, hidden_sizes=list(CLASSIFIER_LAYERS)).to(device).eval()
+    diff = GaussianMultinomialDiffusion(np.array([0]), n_num, net, num_timesteps=T, scheduler="cosine",
+                                        device=torch.device(device)).to(device).eval()
+    return diff, net, clf, make_cond_fn(clf, 1.0)
+
+
+def run_chain(diff, cond_fn, ys, seed, row_offset):
+    """One full guided chain over len(ys) rows, state left on the device (the caller synchronises)."""
+    x, idx = diff._initial_state(len(ys), None, seed, row_offset)
+    keep = diff._run_chain(x, idx, cond_fn, ys, None, seed, row_offset)
+    return x, keep
+
+
+def cpu_baseline(n_num, n_clusters, T, batch, n_steps, threads):
+    """Time `n_steps` guided reverse steps of the CPU oracle at the bench shapes; returns rows/s for a T-step chain."""
+    import numpy as np
+    from oracle import chain, guidance, network, schedule
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from weights import classifier_shapes, mlp_shapes, seeded_state
+    torch.set_num_threads(threads)
+    tb = schedule.tables("cosine", T)
+    p = seeded_state(mlp_shapes(n_num, DENOISER_LAYERS), 1)
+    cp = seeded_state(classifier_shapes(n_num, n_clusters, CLASSIFIER_LAYERS), 2)
+    g = torch.Generator().manual_seed(0)
+    ys = torch.randint(0, n_clusters, (batch, 1), generator=g)
+    nz = {"z0": torch.randn(batch, n_num, generator=g), "noise": torch.randn(n_steps + 1, batch, n_num, generator=g).double()}
+    grad_fn = lambda x, t: guidance.cond_grad(cp, x, t, ys, 1.0)
+    with torch.no_grad():
+        chain.conditional_sample(tb, T, p, n_num, grad_fn, nz, steps=1)            # warm-up step
+        t0 = time.perf_counter()
+        chain.conditional_sample(tb, T, p, n_num, grad_fn, nz, steps=n_steps)
+        dt = time.perf_counter() - t0
+    return batch / (dt / n_steps * T), dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=20000, help="rows per chain per GPU (sampling.batch_size)")
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--n-num", type=int, default=2)
+    ap.add_argument("--clusters", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    from clavaddpm_amd import _lib
+    L = _lib.lib()
+    T, B = args.timesteps, args.batch
+    diff, net, clf, cond_fn = build_workload(device, args.n_num, args.clusters, T)
+    g = torch.Generator().manual_seed(1234 + rank)
+    ys = torch.randint(0, args.clusters, (B, 1), generator=g).to(device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    seed = 20240
+    for w in range(args.warmup):
+        x, keep = run_chain(diff, cond_fn, ys, seed, rank * B)
+        torch.cuda.synchronize()
+
+    # roofline sample: the library brackets its first launches of the timed region with HIP events on the launch stream
+    n_fam = L.clava_prof_family_count()
+    L.clava_prof_family_name.restype = ctypes.c_char_p
+    prof_records = 2048 if rank == 0 else 0
+    if prof_records:
+        _lib.check(L.clava_prof_enable(ctypes.c_int(prof_records)), "clava_prof_enable")
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        x, keep = run_chain(diff, cond_fn, ys, seed + 1 + k, (world * k + rank) * B)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(x).all()), "non-finite samples"
+
+    roofline = None
+    families = {}
+    if prof_records:
+        L.clava_prof_disable()
+        launches = (ctypes.c_int * n_fam)()
+        ms = (ctypes.c_double * n_fam)()
+        fl = (ctypes.c_double * n_fam)()
+        by = (ctypes.c_double * n_fam)()
+        L.clava_prof_collect(launches, ms, fl, by)
+        for f in range(n_fam):
+            if launches[f]:
+                families[L.clava_prof_family_name(f).decode()] = {
+                    "launches": launches[f], "avg_us": 1e3 * ms[f] / launches[f], "ms": ms[f],
+                    "tflops": fl[f] / ms[f] / 1e9 if ms[f] > 0 else 0.0, "gbps": by[f] / ms[f] / 1e6 if ms[f] > 0 else 0.0}
+        dom = "gemm_f32_nt_128x128"
+        if dom in families:
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            f = families[dom]
+            roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT,128x128,vec> (fp32 v_mfma_f32_32x32x2_f32)",
+                        "achieved": round(f["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(f["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
+                        "flops_per_launch": fl[0] / launches[0]}
+
+    rows = world * B * args.steps
+    value = rows / elapsed
+    out = {
+        "metric": f"synth rows/sec ({T}-step reverse diffusion)", "value": round(value, 1), "unit": "rows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "movie_lens (movie->rating) cluster-guided sampling, configs/movie_lens.json shapes",
+                   "rows_per_gpu_per_step": B, "timesteps": T, "n_num": args.n_num, "clusters": args.clusters,
+                   "denoiser": DENOISER_LAYERS, "classifier": CLASSIFIER_LAYERS, "guidance_scale": 1.0,
+                   "parallelism": f"rows sharded over {world} GPU(s), no data-path collective"},
+        "roofline": roofline,
+    }
+    if families:
+        out["kernel_families"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
+                                      "tflops": round(v["tflops"], 2), "gbps": round(v["gbps"], 1)} for k, v in families.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        cb = min(B, 20000)
+        v, dt = cpu_baseline(args.n_num, args.clusters, T, cb, args.cpu_steps, threads)
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "rows/s", "cores": threads, "kind": "port",
+                               "sample": f"{args.cpu_steps} guided reverse steps (t={T - 1}..{T - args.cpu_steps}) on {cb} rows, "
+                                         f"same networks; {dt:.1f} s of CPU work, extrapolated to {T} steps"}
+        out["speedup_vs_cpu"] = round(value / v, 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,10 @@ def lib():
             raise ClavaHipError(
                 f"{LIB_PATH} is missing: build it with `python clavaddpm_amd/csrc/build.py` "
                 "(there is no CPU fallback for the HIP path)")
+        # torch ships its own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's).  Import torch first so that
+        # this library binds to the HIP runtime torch already loaded; the other order puts two HSA runtimes into one
+        # process and the second one sees no device.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.clava_last_error.restype = ctypes.c_char_p
         L.clava_version.restype = ctypes.c_int

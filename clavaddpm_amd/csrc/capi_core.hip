@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "clava_hip.h"
 #include "common.h"
 
@@ -14,7 +16,76 @@ void clava_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- per-launch timing ------------------------------------------------------------------------------------------------
+bool g_clava_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int family; double flops, bytes; };
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+bool g_prof_open = false;
+const char* const kFamilyNames[PROF_N_FAMILIES] = {
+    "gemm_f32_nt_128x128", "gemm_f32_nt_64x64", "gemm_f32_nn_128x128", "gemm_f32_nn_64x64", "gemm_f32_tn_128x128",
+    "gemm_f32_tn_64x64", "gauss_step", "multinomial_step", "logsoftmax_select_grad", "misc", "mixed_loss", "adamw_ema",
+    "gmm_estep"};
+}  // namespace
+
+void clava_prof_begin_(int family, double flops, double bytes, hipStream_t stream) {
+    g_prof_open = false;
+    if (g_prof_used >= g_prof.size()) return;
+    ProfRec& r = g_prof[g_prof_used];
+    r.family = family; r.flops = flops; r.bytes = bytes;
+    if (hipEventRecord(r.a, stream) == hipSuccess) g_prof_open = true;
+}
+void clava_prof_end_(hipStream_t stream) {
+    if (!g_prof_open) return;
+    if (hipEventRecord(g_prof[g_prof_used].b, stream) == hipSuccess) ++g_prof_used;
+    g_prof_open = false;
+}
+
 extern "C" {
+
+int clava_prof_enable(int max_records) {
+    CLAVA_CHECK_ARG(max_records > 0 && max_records <= (1 << 20), "prof_enable: max_records out of range");
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof.resize(max_records);
+    for (auto& r : g_prof) {
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            clava_set_error("prof_enable: hipEventCreate failed");
+            return CLAVA_ERR_LAUNCH;
+        }
+    }
+    g_prof_used = 0;
+    g_clava_prof_on = true;
+    return CLAVA_OK;
+}
+
+int clava_prof_disable(void) {
+    g_clava_prof_on = false;
+    return CLAVA_OK;
+}
+
+int clava_prof_family_count(void) { return PROF_N_FAMILIES; }
+
+const char* clava_prof_family_name(int family) {
+    return (family >= 0 && family < PROF_N_FAMILIES) ? kFamilyNames[family] : "";
+}
+
+int clava_prof_collect(int* launches, double* total_ms, double* total_flops, double* total_bytes) {
+    CLAVA_CHECK_ARG(launches && total_ms && total_flops && total_bytes, "prof_collect: null output");
+    for (int f = 0; f < PROF_N_FAMILIES; ++f) { launches[f] = 0; total_ms[f] = total_flops[f] = total_bytes[f] = 0.0; }
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        const ProfRec& r = g_prof[i];
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        launches[r.family] += 1;
+        total_ms[r.family] += ms;
+        total_flops[r.family] += r.flops;
+        total_bytes[r.family] += r.bytes;
+    }
+    return (int)g_prof_used;
+}
 
 int clava_version(void) { return CLAVA_HIP_VERSION; }
 

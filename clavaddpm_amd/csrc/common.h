@@ -27,6 +27,27 @@ void clava_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+// ---- optional per-launch timing (clava_prof_* in include/clava_hip.h) -----------------------------------------------
+// When enabled, every kernel launch of the library is bracketed by two hipEvents on its own stream and tagged with
+// its kernel family and algorithmic work; bench.py reads the totals for the roofline line.  Disabled: one branch.
+enum ProfFamily {
+    PROF_GEMM_NT_128 = 0, PROF_GEMM_NT_64, PROF_GEMM_NN_128, PROF_GEMM_NN_64, PROF_GEMM_TN_128, PROF_GEMM_TN_64,
+    PROF_GAUSS_STEP, PROF_MULTI_STEP, PROF_SELECT_GRAD, PROF_MISC, PROF_LOSS, PROF_ADAMW, PROF_GMM, PROF_N_FAMILIES
+};
+extern bool g_clava_prof_on;
+void clava_prof_begin_(int family, double flops, double bytes, hipStream_t stream);
+void clava_prof_end_(hipStream_t stream);
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(int family, double flops, double bytes, hipStream_t stream) : s(stream), on(g_clava_prof_on) {
+        if (on) clava_prof_begin_(family, flops, bytes, stream);
+    }
+    ~ProfScope() {
+        if (on) clava_prof_end_(s);
+    }
+};
+
 // activation codes shared by the GEMM epilogue and the host side
 enum { CLAVA_ACT_NONE = 0, CLAVA_ACT_RELU = 1, CLAVA_ACT_LEAKY = 2, CLAVA_ACT_SILU = 3 };
 

@@ -269,6 +269,8 @@ int clava_launch_gauss_step(const GaussStepArgs& a, hipStream_t stream) {
     CLAVA_CHECK_ARG(a.t_rows || (a.t >= 0 && a.t < a.s.T), "gauss_step: t=%d outside [0,%d)", a.t, a.s.T);
     const long long n = (long long)a.B * a.n_num;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    // algorithmic bytes per element: eps 4 + x 8 in + 8 out + x_in 4 (+ grad 4) (+ injected noise 8)
+    ProfScope prof(PROF_GAUSS_STEP, 0.0, (double)n * (24 + (a.grad ? 4 : 0) + (a.noise ? 8 : 0)), stream);
     hipLaunchKernelGGL(gauss_step_kernel, dim3(grid), dim3(256), 0, stream, a);
     CLAVA_CHECK_LAUNCH("clava_gauss_step");
     return CLAVA_OK;
@@ -283,6 +285,8 @@ int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
     const long long pairs = (long long)a.B * a.m;
     const long long blocks = (pairs + 3) / 4;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    // algorithmic bytes: logits 4/class in, log-one-hot 4/class out (+ injected uniforms 4/class), indices 4+4 per feature
+    ProfScope prof(PROF_MULTI_STEP, 0.0, (double)a.B * ((double)a.sumK * ((a.logits ? 4 : 0) + (a.x_in ? 4 : 0) + (a.uniforms ? 4 : 0)) + 8.0 * a.m), stream);
     hipLaunchKernelGGL(multinomial_step_kernel, dim3(grid), dim3(256), 0, stream, a);
     CLAVA_CHECK_LAUNCH("clava_multinomial_step");
     return CLAVA_OK;

@@ -32,6 +32,17 @@ int clava_version(void);
 const char* clava_last_error(void);
 int clava_device_count(void); /* host-only probe: number of HIP devices, 0 when there is none */
 
+/* ---- per-launch timing (measurement only; no counterpart in the reference) ------------------------------------
+ * clava_prof_enable(n) makes the library bracket each of its next n kernel launches with two hipEvents on the
+ * launch's own stream and tag it with its kernel family and algorithmic FLOPs / bytes; clava_prof_collect waits for
+ * the recorded events and returns per-family totals (arrays of clava_prof_family_count() entries) and the number of
+ * launches recorded.  bench.py uses it for the `roofline` object.  Not thread-safe; host-side only. */
+int clava_prof_enable(int max_records);
+int clava_prof_disable(void);
+int clava_prof_family_count(void);
+const char* clava_prof_family_name(int family);
+int clava_prof_collect(int* launches, double* total_ms, double* total_flops, double* total_bytes);
+
 /* ---- dense layers -------------------------------------------------------------------------------------------
  * y[M,N] = act( (x*in_scale + in_shift)[M,K] . w[N,K]^T + bias[N] + rowadd[M,N] )
  * Replaces nn.Linear (+ReLU / LeakyReLU / SiLU) of MLPDiffusion (tab_ddpm/modules.py:153-158, 191, 444-449, 459)
