@@ -163,11 +163,11 @@ def main():
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             f = families[dom]
-            roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<NT,128x128,vec> (fp32 v_mfma_f32_32x32x2_f32)",
+            roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<true,true,128,128,true,false> (fp32 v_mfma_f32_32x32x2_f32; the denoiser's layers)",
                         "achieved": round(f["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(f["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
-                        "flops_per_launch": fl[0] / launches[0]}
+                        "flops_per_launch": round(fl[0] / launches[0])}
 
     rows = world * B * args.steps
     value = rows / elapsed

@@ -24,8 +24,8 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 bool g_prof_open = false;
 const char* const kFamilyNames[PROF_N_FAMILIES] = {
-    "gemm_f32_nt_128x128", "gemm_f32_nt_64x64", "gemm_f32_nn_128x128", "gemm_f32_nn_64x64", "gemm_f32_tn_128x128",
-    "gemm_f32_tn_64x64", "gauss_step", "multinomial_step", "logsoftmax_select_grad", "misc", "mixed_loss", "adamw_ema",
+    "gemm_f32_nt_128x128", "gemm_f32_nt_64x64", "gemm_f32_nt_128x128_bn", "gemm_f32_nt_64x64_bn", "gemm_f32_nn_128x128",
+    "gemm_f32_nn_64x64", "gemm_f32_tn_128x128", "gemm_f32_tn_64x64", "gauss_step", "multinomial_step", "logsoftmax_select_grad", "misc", "mixed_loss", "adamw_ema",
     "gmm_estep"};
 }  // namespace
 
@@ -128,12 +128,13 @@ int clava_gemm_dgrad_f32(const float* dy, int lddy, const float* w, int ldw, con
     return clava_launch_gemm_f32(dy, lddy, true, w, ldw, false, dx, lddx, M, K_in, N_out, e, 1, 0, (hipStream_t)stream);
 }
 
-int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, float* dw_slabs, int lddw, int M,
-                         int N_out, int K_in, int splits, void* stream) {
+int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, float* dw_slabs, int lddw,
+                         long long slab_stride, int M, int N_out, int K_in, int splits, void* stream) {
+    CLAVA_CHECK_ARG(splits == 1 || slab_stride >= (long long)(N_out - 1) * lddw + K_in, "gemm_wgrad: slab_stride too small");
     GemmEpi e = gemm_epi_plain();
     // dw[N_out, K_in] = dy^T[N_out, M] * x[M, K_in]: contraction over the batch M; both operands MN-major
     return clava_launch_gemm_f32(dy, lddy, false, x, ldx, false, dw_slabs, lddw, N_out, K_in, M, e, splits,
-                                 (long)N_out * lddw, (hipStream_t)stream);
+                                 (long)slab_stride, (hipStream_t)stream);
 }
 
 }  // extern "C"

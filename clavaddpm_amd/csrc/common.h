@@ -31,7 +31,8 @@ void clava_set_error(const char* fmt, ...);
 // When enabled, every kernel launch of the library is bracketed by two hipEvents on its own stream and tagged with
 // its kernel family and algorithmic work; bench.py reads the totals for the roofline line.  Disabled: one branch.
 enum ProfFamily {
-    PROF_GEMM_NT_128 = 0, PROF_GEMM_NT_64, PROF_GEMM_NN_128, PROF_GEMM_NN_64, PROF_GEMM_TN_128, PROF_GEMM_TN_64,
+    PROF_GEMM_NT_128 = 0, PROF_GEMM_NT_64, PROF_GEMM_NT_128_BN, PROF_GEMM_NT_64_BN, PROF_GEMM_NN_128, PROF_GEMM_NN_64,
+    PROF_GEMM_TN_128, PROF_GEMM_TN_64,
     PROF_GAUSS_STEP, PROF_MULTI_STEP, PROF_SELECT_GRAD, PROF_MISC, PROF_LOSS, PROF_ADAMW, PROF_GMM, PROF_N_FAMILIES
 };
 extern bool g_clava_prof_on;

@@ -299,7 +299,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 template <bool AK, bool BKM, int BM, int BN>
 int launch_tiles(const GemmArgs& g, bool vec, int splitk, hipStream_t stream) {
     dim3 grid(g.tiles_m * g.tiles_n, splitk, 1);
-    const int fam = (AK && BKM ? PROF_GEMM_NT_128 : (AK ? PROF_GEMM_NN_128 : PROF_GEMM_TN_128)) + (BM == 64 ? 1 : 0);
+    const int fam = (AK && BKM ? (g.e.a_scale ? PROF_GEMM_NT_128_BN : PROF_GEMM_NT_128) : (AK ? PROF_GEMM_NN_128 : PROF_GEMM_TN_128)) +
+                    (BM == 64 ? 1 : 0);
     ProfScope prof(fam, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * splitk), stream);
     const bool aff = g.e.a_scale != nullptr;
     if (AK && BKM && aff) {

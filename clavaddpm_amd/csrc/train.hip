@@ -1,0 +1,341 @@
+// Training-side kernels: fused loss + loss gradient, SiLU forward/backward for the time-embedding branch,
+// bias gradients, deterministic slab reduction and the fused AdamW + EMA update.
+//
+// Replaces, per training step (scripts/train.py:30-40, 69): `_gaussian_loss` 'mse' (tab_ddpm/
+// gaussian_multinomial_diffsuion.py:282-300), `_multinomial_loss` = compute_Lt + kl_prior (:544-572, 597-607) with
+// their autograd backward down to the denoiser output, torch.optim.AdamW.step (scripts/train.py:17, 38) and
+// update_ema (scripts/utils_train.py:20-29).  Every reduction runs in a fixed order: results are bitwise
+// reproducible from run to run (no float atomics).
+#include "rng.h"
+#include "step.h"
+
+namespace {
+
+constexpr float LOG_TINY = -69.07755279541016f;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float log_add_exp(float x, float y) {
+    const float m = fmaxf(x, y);
+    return m + logf(1.0f + expf(-fabsf(x - y)));
+}
+
+// ---------------------------------------------------------------------------------------------- Gaussian MSE loss
+// loss_rows[b] = mean_c (noise - out)^2 ; d_out[b, c] = 2 (out - noise) / (n_num * B)     (:287-288 and its backward)
+__global__ void __launch_bounds__(256) gauss_mse_kernel(int B, int n, const float* __restrict__ out, int ld_out,
+                                                        const float* __restrict__ noise, float* __restrict__ loss_rows,
+                                                        float* __restrict__ d_out, int ld_d) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B) return;
+    const float gscale = 2.0f / ((float)n * (float)B);
+    float acc = 0.f;
+    for (int c = 0; c < n; ++c) {
+        const float d = noise[(size_t)row * n + c] - out[(size_t)row * ld_out + c];
+        acc += d * d;
+        d_out[(size_t)row * ld_d + c] = -d * gscale;
+    }
+    loss_rows[row] = acc / (float)n;
+}
+
+// ---------------------------------------------------------------------------------------------- multinomial loss
+struct MLossArgs {
+    ScheduleDev s;
+    int B, m, sumK;
+    const float* logits; int ld_logits;   // denoiser output, categorical columns
+    const int* idx0;                      // [B, m] clean categories
+    const int* idxt;                      // [B, m] noised categories (q_sample)
+    const long long* t_rows;
+    const int* offsets; const float* log_k;
+    float pt;                             // 1 / T as float32 ('uniform' sample_time, :589-593)
+    float* loss_terms;                    // [B, m]: Lt / pt + kl_prior of this (row, feature) block
+    float* d_logits; int ld_d;            // gradient of mean_b( sum_f loss_terms / m ) w.r.t. logits
+};
+
+struct LBlock {
+    const float* lg;
+    int K, hot0, hott, t;
+    float mx, lsum, logk;
+    float lca_p, l1mca_p, la_t, l1ma_t, lca_T, l1mca_T;
+    __device__ __forceinline__ float lp(int c) const { return (lg[c] - mx) - lsum; }                       // predict_start
+    __device__ __forceinline__ float q1(int c) const {                                                     // q_pred_one_timestep(x_t)
+        return log_add_exp((c == hott ? 0.f : LOG_TINY) + la_t, l1ma_t - logk);
+    }
+    __device__ __forceinline__ float ev(float lstart) const {                                              // q_pred(., t-1) or identity at t = 0
+        return t == 0 ? lstart : log_add_exp(lstart + lca_p, l1mca_p - logk);
+    }
+    __device__ __forceinline__ float un_model(int c) const { return ev(lp(c)) + q1(c); }
+    __device__ __forceinline__ float un_true(int c) const { return ev(c == hot0 ? 0.f : LOG_TINY) + q1(c); }
+};
+
+__global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long n_pairs = (long long)a.B * a.m;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int T = a.s.T;
+    for (long long pair = wave0; pair < n_pairs; pair += n_waves) {
+        const int row = (int)(pair / a.m), f = (int)(pair - (long long)row * a.m);
+        const int o = a.offsets[f];
+        LBlock b;
+        b.K = a.offsets[f + 1] - o;
+        b.logk = a.log_k[f];
+        b.t = (int)a.t_rows[row];
+        b.hot0 = a.idx0[(size_t)row * a.m + f];
+        b.hott = a.idxt[(size_t)row * a.m + f];
+        b.lg = a.logits + (size_t)row * a.ld_logits + o;
+        const int tp = max(b.t - 1, 0);
+        b.lca_p = a.s.log_cumprod_alpha[tp];   b.l1mca_p = a.s.log_1_min_cumprod_alpha[tp];
+        b.la_t = a.s.log_alpha[b.t];           b.l1ma_t = a.s.log_1_min_alpha[b.t];
+        b.lca_T = a.s.log_cumprod_alpha[T - 1]; b.l1mca_T = a.s.log_1_min_cumprod_alpha[T - 1];
+        // log-softmax statistics of the logits
+        float mx = -INFINITY;
+        for (int c = lane; c < b.K; c += 64) mx = fmaxf(mx, b.lg[c]);
+        b.mx = wave_max(mx);
+        float sm = 0.f;
+        for (int c = lane; c < b.K; c += 64) sm += expf(b.lg[c] - b.mx);
+        b.lsum = logf(wave_sum(sm));
+        // normalisers of the model and true posteriors (direct per-block log-sum-exp)
+        float mm = -INFINITY, mt = -INFINITY;
+        for (int c = lane; c < b.K; c += 64) { mm = fmaxf(mm, b.un_model(c)); mt = fmaxf(mt, b.un_true(c)); }
+        mm = wave_max(mm); mt = wave_max(mt);
+        float sm_m = 0.f, sm_t = 0.f;
+        for (int c = lane; c < b.K; c += 64) { sm_m += expf(b.un_model(c) - mm); sm_t += expf(b.un_true(c) - mt); }
+        const float lse_m = mm + logf(wave_sum(sm_m)), lse_t = mt + logf(wave_sum(sm_t));
+        // loss terms: KL(true || model) (t > 0) or decoder NLL (t == 0) (:555-572), and the prior KL (:544-553)
+        float W = 0.f, loss = 0.f, klp = 0.f;
+        for (int c = lane; c < b.K; c += 64) {
+            const float lm = b.un_model(c) - lse_m;
+            if (b.t == 0) {
+                const float w = (c == b.hot0) ? 1.0f : 1e-30f;        // exp(log_x_start)
+                W += w;
+                loss -= w * lm;
+            } else {
+                const float lt = b.un_true(c) - lse_t;
+                const float w = expf(lt);
+                W += w;
+                loss += w * (lt - lm);
+            }
+            const float lq = log_add_exp((c == b.hot0 ? 0.f : LOG_TINY) + b.lca_T, b.l1mca_T - b.logk);
+            klp += expf(lq) * (lq + b.logk);
+        }
+        W = wave_sum(W); loss = wave_sum(loss); klp = wave_sum(klp);
+        if (lane == 0) a.loss_terms[(size_t)row * a.m + f] = loss / a.pt + klp;
+        // backward: d loss / d un_model(j) = -w(j) + W * exp(lm(j)); through ev (sigmoid of the log-add-exp) and log-softmax
+        float S = 0.f;
+        for (int c = lane; c < b.K; c += 64) {
+            const float lpc = b.lp(c), evc = b.ev(lpc);
+            const float lm = (evc + b.q1(c)) - lse_m;
+            const float w = (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : expf(b.un_true(c) - lse_t);
+            const float g_un = -w + W * expf(lm);
+            S += g_un * (b.t == 0 ? 1.0f : expf((lpc + b.lca_p) - evc));
+        }
+        S = wave_sum(S);
+        const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
+        float* d = a.d_logits + (size_t)row * a.ld_d + o;
+        for (int c = lane; c < b.K; c += 64) {
+            const float lpc = b.lp(c), evc = b.ev(lpc);
+            const float lm = (evc + b.q1(c)) - lse_m;
+            const float w = (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : expf(b.un_true(c) - lse_t);
+            const float g_lp = (-w + W * expf(lm)) * (b.t == 0 ? 1.0f : expf((lpc + b.lca_p) - evc));
+            d[c] = (g_lp - expf(lpc) * S) * scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- reductions
+// out[0] = scale * sum(v[0..n)) in a fixed order (one workgroup: per-thread strided partials, then an LDS tree)
+__global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ v, long long n, float scale, float* __restrict__ out) {
+    __shared__ float part[1024];
+    float acc = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] * scale;
+}
+
+// db_slabs[s][n] = sum over the s-th batch range of dy[:, n]: bias gradients, same split scheme as the weight slabs
+__global__ void __launch_bounds__(256) colsum_slabs_kernel(const float* __restrict__ dy, int ld, int M, int N, int splits,
+                                                           float* __restrict__ slabs, long long slab_stride) {
+    __shared__ float part[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int rows_per = (M + splits - 1) / splits;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float acc = 0.f;
+    if (col < N)
+        for (int r = r0 + q; r < r1; r += 4) acc += dy[(size_t)r * ld + col];
+    part[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && col < N)
+        slabs[(size_t)blockIdx.y * slab_stride + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// out[i] = scale * sum_s slabs[s][i]
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S, long long stride, long long n,
+                                                          float scale, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        for (int s = 0; s < S; ++s) g += slabs[(size_t)s * stride + i];
+        out[i] = g * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- SiLU
+__global__ void __launch_bounds__(256) silu_kernel(const float* __restrict__ z, float* __restrict__ a, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = z[i];
+        a[i] = v / (1.0f + expf(-v));
+    }
+}
+// dz = da * sigmoid(z) * (1 + z * (1 - sigmoid(z)))
+__global__ void __launch_bounds__(256) silu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ da,
+                                                       float* __restrict__ dz, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = z[i];
+        const float sg = 1.0f / (1.0f + expf(-v));
+        dz[i] = da[i] * (sg * (1.0f + v * (1.0f - sg)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- AdamW + EMA
+struct AdamArgs {
+    float* p; float* ema; float* m; float* v;
+    const float* g; int S; long long stride; float gscale;   // gradient = gscale * sum_s g[s * stride + i]
+    long long n;
+    float lr_wd;       // lr * weight_decay
+    float beta1_c;     // 1 - beta1
+    float beta2, beta2_c;
+    float step_size;   // lr / (1 - beta1^step)
+    float bc2_sqrt;    // sqrt(1 - beta2^step)
+    float eps;
+    float ema_rate, ema_c;
+};
+
+// torch.optim.AdamW single-tensor update order: decay, lerp first moment, second moment, bias-corrected step; then the EMA
+__global__ void __launch_bounds__(256) adamw_ema_kernel(AdamArgs a) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        for (int s = 0; s < a.S; ++s) g += a.g[(size_t)s * a.stride + i];
+        g *= a.gscale;
+        float p = a.p[i];
+        p = p * (1.0f - a.lr_wd);
+        float m = a.m[i];
+        m = m + a.beta1_c * (g - m);
+        float v = a.v[i];
+        v = v * a.beta2 + a.beta2_c * (g * g);
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        p = p - a.step_size * (m / denom);
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        if (a.ema) a.ema[i] = a.ema[i] * a.ema_rate + p * a.ema_c;
+    }
+}
+
+inline int grid_for(long long n, int cap = 4096) {
+    const long long b = (n + 255) / 256;
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int clava_gauss_mse_loss_f32(int B, int n_num, const float* model_out, int ld_out, const float* noise, float* loss_rows,
+                             float* d_out, int ld_d, void* stream) {
+    CLAVA_CHECK_ARG(B > 0 && n_num > 0 && model_out && noise && loss_rows && d_out, "gauss_mse_loss: bad arguments");
+    ProfScope prof(PROF_LOSS, 0.0, 12.0 * B * n_num, (hipStream_t)stream);
+    hipLaunchKernelGGL(gauss_mse_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n_num, model_out, ld_out,
+                       noise, loss_rows, d_out, ld_d);
+    CLAVA_CHECK_LAUNCH("clava_gauss_mse_loss_f32");
+    return CLAVA_OK;
+}
+
+int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int sumK, const int* offsets, const float* log_k,
+                               const float* logits, int ld_logits, const int* idx0, const int* idxt,
+                               const long long* t_rows, float pt, float* loss_terms, float* d_logits, int ld_d,
+                               void* stream) {
+    CLAVA_CHECK_ARG(sched && B > 0 && m > 0 && sumK > 0 && offsets && log_k && logits && idx0 && idxt && t_rows && loss_terms && d_logits,
+                    "multinomial_loss: bad arguments");
+    MLossArgs a;
+    a.s = *sched; a.B = B; a.m = m; a.sumK = sumK; a.logits = logits; a.ld_logits = ld_logits; a.idx0 = idx0; a.idxt = idxt;
+    a.t_rows = t_rows; a.offsets = offsets; a.log_k = log_k; a.pt = pt; a.loss_terms = loss_terms; a.d_logits = d_logits; a.ld_d = ld_d;
+    const long long blocks = ((long long)B * m + 3) / 4;
+    ProfScope prof(PROF_LOSS, 0.0, 8.0 * B * sumK, (hipStream_t)stream);
+    hipLaunchKernelGGL(multinomial_loss_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    CLAVA_CHECK_LAUNCH("clava_multinomial_loss_f32");
+    return CLAVA_OK;
+}
+
+int clava_sum_f32(const float* v, long long n, float scale, float* out, void* stream) {
+    CLAVA_CHECK_ARG(v && out && n > 0, "sum: bad arguments");
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, scale, out);
+    CLAVA_CHECK_LAUNCH("clava_sum_f32");
+    return CLAVA_OK;
+}
+
+int clava_colsum_slabs_f32(const float* dy, int lddy, int M, int N, int splits, float* db_slabs, long long slab_stride,
+                           void* stream) {
+    CLAVA_CHECK_ARG(dy && db_slabs && M > 0 && N > 0 && splits >= 1 && splits <= 64 && lddy >= N, "colsum_slabs: bad arguments");
+    ProfScope prof(PROF_MISC, 0.0, 4.0 * M * N, (hipStream_t)stream);
+    hipLaunchKernelGGL(colsum_slabs_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, dy, lddy, M, N, splits,
+                       db_slabs, slab_stride);
+    CLAVA_CHECK_LAUNCH("clava_colsum_slabs_f32");
+    return CLAVA_OK;
+}
+
+int clava_slab_reduce_f32(const float* slabs, int splits, long long slab_stride, long long n, float scale, float* out,
+                          void* stream) {
+    CLAVA_CHECK_ARG(slabs && out && splits >= 1 && n > 0, "slab_reduce: bad arguments");
+    ProfScope prof(PROF_MISC, 0.0, 4.0 * n * (splits + 1), (hipStream_t)stream);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, slabs, splits, slab_stride, n,
+                       scale, out);
+    CLAVA_CHECK_LAUNCH("clava_slab_reduce_f32");
+    return CLAVA_OK;
+}
+
+int clava_silu_f32(const float* z, float* a, long long n, void* stream) {
+    CLAVA_CHECK_ARG(z && a && n > 0, "silu: bad arguments");
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, a, n);
+    CLAVA_CHECK_LAUNCH("clava_silu_f32");
+    return CLAVA_OK;
+}
+
+int clava_silu_backward_f32(const float* z, const float* da, float* dz, long long n, void* stream) {
+    CLAVA_CHECK_ARG(z && da && dz && n > 0, "silu_backward: bad arguments");
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, da, dz, n);
+    CLAVA_CHECK_LAUNCH("clava_silu_backward_f32");
+    return CLAVA_OK;
+}
+
+int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg_sq, const float* grad_slabs, int splits,
+                        long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, long long step, double ema_rate, void* stream) {
+    CLAVA_CHECK_ARG(param && exp_avg && exp_avg_sq && grad_slabs && splits >= 1 && n > 0 && step >= 1, "adamw_ema: bad arguments");
+    AdamArgs a;
+    a.p = param; a.ema = ema; a.m = exp_avg; a.v = exp_avg_sq; a.g = grad_slabs; a.S = splits; a.stride = slab_stride;
+    a.gscale = grad_scale; a.n = n;
+    a.lr_wd = (float)(lr * weight_decay);
+    a.beta1_c = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2; a.beta2_c = (float)(1.0 - beta2);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = (float)eps;
+    a.ema_rate = (float)ema_rate; a.ema_c = (float)(1.0 - ema_rate);
+    ProfScope prof(PROF_ADAMW, 0.0, 4.0 * n * (7 + splits + (ema ? 2 : 0)), (hipStream_t)stream);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    CLAVA_CHECK_LAUNCH("clava_adamw_ema_f32");
+    return CLAVA_OK;
+}
+
+}  // extern "C"

@@ -73,8 +73,9 @@ def linear_dgrad(dy, w, act_out=None, slope=0.0, col_scale=None, alpha=1.0, out=
     return out
 
 
-def linear_wgrad(dy, x, splits=1, out=None):
-    """Partial products of dy.T @ x over `splits` batch ranges: returns [splits, N_out, K_in]."""
+def linear_wgrad(dy, x, splits=1, out=None, slab_stride=None):
+    """Partial products of dy.T @ x over `splits` batch ranges: returns [splits, N_out, K_in] (or fills `out`, whose
+    slabs are `slab_stride` floats apart)."""
     require_cuda(dy, x)
     dy, x = _f32c(dy, "dy"), _f32c(x, "x")
     M, N = dy.shape
@@ -83,6 +84,9 @@ def linear_wgrad(dy, x, splits=1, out=None):
         raise _lib.ClavaHipError("linear_wgrad: batch mismatch")
     if out is None:
         out = torch.empty((splits, N, K), device=dy.device, dtype=torch.float32)
+    if slab_stride is None:
+        slab_stride = N * K
     check(lib().clava_gemm_wgrad_f32(ptr(dy), c_int(dy.stride(0)), ptr(x), c_int(x.stride(0)), ptr(out), c_int(K),
-                                     c_int(M), c_int(N), c_int(K), c_int(splits), stream_ptr()), "clava_gemm_wgrad_f32")
+                                     _lib.c_long(slab_stride), c_int(M), c_int(N), c_int(K), c_int(splits), stream_ptr()),
+          "clava_gemm_wgrad_f32")
     return out

@@ -1,0 +1,145 @@
+"""`Trainer` with the reference's constructor, attributes and loop semantics (`scripts/train.py:7-71`), fused on the HIP library.
+
+Same observable behaviour: AdamW(lr, weight_decay) on the denoiser, linear LR anneal applied AFTER each step (so
+step 0 runs at the full lr, `:24-28, 53`), EMA(0.999) of the denoiser updated every step (`:69`), `loss_history`
+rows every `log_every` steps with losses rounded to 4 decimals (`:59-67`).
+
+What differs by design:
+  * one step = q-sample kernels -> denoiser forward -> fused loss/gradient kernels -> backward GEMMs writing gradient
+    slabs -> ONE fused AdamW+EMA kernel over a flat parameter buffer (the reference: autograd graph, ~60 optimizer
+    launches, 40 EMA launches);
+  * no host synchronisation per step: the reference calls `.item()` twice per step (`:56-57`); here the running loss
+    sums stay on the device and are read once every `log_every` steps;
+  * data parallelism (new): when torch.distributed is initialised, the flat gradient is averaged
+    with one RCCL all-reduce per step; parameters are broadcast from rank 0 at construction.
+"""
+from copy import deepcopy
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .. import training as _tr
+from .._lib import c_float, c_int, check, lib, ptr, stream_ptr
+from ..training import c_ll
+
+
+class Trainer:
+    def __init__(self, diffusion, train_iter, lr, weight_decay, steps, device=torch.device('cuda:0')):
+        self.diffusion = diffusion
+        self.train_iter = train_iter
+        self.steps = steps
+        self.init_lr = lr
+        self.lr = lr
+        self.weight_decay = weight_decay
+        self.device = device
+        self.loss_history = pd.DataFrame(columns=['step', 'mloss', 'gloss', 'loss'])
+        self.log_every = 100
+        self.print_every = 500
+        self.ema_every = 1000
+        self.betas = (0.9, 0.999)
+        self.eps = 1e-8
+        self.ema_rate = 0.999
+        self.opt_step = 0
+
+        net = diffusion._denoise_fn
+        self.layout = _tr.FlatLayout(net)
+        dev = next(net.parameters()).device
+        total = self.layout.total
+        # one flat buffer per role; while training, the module's parameters are views into `flat`
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._flattened = False
+        self._flatten()
+        self.world = 1
+        self.dist = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self.dist = torch.distributed
+            self.world = self.dist.get_world_size()
+            self.dist.broadcast(self.flat, src=0)
+        self.ema_model = deepcopy(net)
+        self.ema_flat = self.flat.clone()
+        for name, p in self.ema_model.named_parameters():
+            p.detach_()
+            p.data = self.layout.view(self.ema_flat, name)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.slabs = torch.zeros((_tr.GRAD_SPLITS, total), device=dev, dtype=torch.float32)
+        self.grad_flat = torch.zeros(total, device=dev, dtype=torch.float32) if self.dist is not None else None
+
+    def _flatten(self):
+        if self._flattened:
+            return
+        for name, p in self.diffusion._denoise_fn.named_parameters():
+            v = self.layout.view(self.flat, name)
+            v.copy_(p.data)
+            p.data = v
+        self._flattened = True
+
+    def finalize(self):
+        """Give every parameter its own storage again (the whole diffusion object is pickled after training,
+        complex_pipeline.py:64,78; views into one 17 MB buffer would be serialised once per parameter)."""
+        if not self._flattened:
+            return
+        for p in list(self.diffusion._denoise_fn.parameters()) + list(self.ema_model.parameters()):
+            p.data = p.data.clone()
+        self._flattened = False
+
+    def _anneal_lr(self, step):
+        frac_done = step / self.steps
+        self.lr = self.init_lr * (1 - frac_done)
+
+    def _run_step(self, x, out_dict, draws=None):
+        d = self.diffusion
+        net = d._denoise_fn
+        if not self._flattened:
+            self._flatten()
+            for name, p in self.ema_model.named_parameters():
+                v = self.layout.view(self.ema_flat, name)
+                v.copy_(p.data)
+                p.data = v
+        x = x.to(self.device)
+        t, noise, u, seed = _tr.draw(d, x, draws)
+        x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
+        model_out, saved = _tr.denoiser_forward(net, x_in, t)
+        loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+        _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs)
+        self.opt_step += 1
+        if self.dist is not None:
+            _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
+            self.dist.all_reduce(self.grad_flat)             # RCCL sum over ranks of the pre-scaled flat gradient
+            g, S, stride = self.grad_flat, 1, self.layout.total
+        else:
+            g, S, stride = self.slabs, _tr.GRAD_SPLITS, self.layout.total
+        import ctypes
+        check(lib().clava_adamw_ema_f32(ptr(self.flat), ptr(self.ema_flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(g), c_int(S),
+                                        c_ll(stride), c_float(1.0), c_ll(self.layout.total), ctypes.c_double(self.lr),
+                                        ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
+                                        ctypes.c_double(self.weight_decay), c_ll(self.opt_step), ctypes.c_double(self.ema_rate),
+                                        stream_ptr()), "clava_adamw_ema_f32")
+        zero = torch.zeros((), device=x.device)
+        return (loss_multi if loss_multi is not None else zero), (loss_gauss if loss_gauss is not None else zero)
+
+    def run_loop(self):
+        step = 0
+        dev = self.flat.device
+        sums = torch.zeros(2, device=dev, dtype=torch.float64)     # running loss_multi * n, loss_gauss * n (on the device)
+        curr_count = 0
+        while step < self.steps:
+            x, out_dict = next(self.train_iter)
+            out_dict = {'y': out_dict}
+            batch_loss_multi, batch_loss_gauss = self._run_step(x, out_dict)
+            self._anneal_lr(step)
+            curr_count += len(x)
+            sums[0] += batch_loss_multi.double() * len(x)
+            sums[1] += batch_loss_gauss.double() * len(x)
+            if (step + 1) % self.log_every == 0:
+                m, g = (sums / curr_count).tolist()                  # the only host sync, once per log_every steps
+                mloss = np.around(m, 4)
+                gloss = np.around(g, 4)
+                if (step + 1) % self.print_every == 0:
+                    print(f'Step {(step + 1)}/{self.steps} MLoss: {mloss} GLoss: {gloss} Sum: {mloss + gloss}')
+                self.loss_history.loc[len(self.loss_history)] = [step + 1, mloss, gloss, mloss + gloss]
+                curr_count = 0
+                sums.zero_()
+            step += 1
+        self.finalize()

@@ -1,0 +1,265 @@
+"""Denoiser training on the HIP library: forward with saved activations, fused losses, backward GEMMs.
+
+Two callers share this core:
+  * the compat path - `GaussianMultinomialDiffusion.mixed_loss` / `MLPDiffusion.forward` under autograd return ordinary
+    differentiable tensors (two `torch.autograd.Function`s whose backward runs the HIP kernels), so the reference's
+    own training loop (`scripts/train.py:30-40`: zero_grad, mixed_loss, backward, torch AdamW) works unchanged;
+  * the fused path - `clavaddpm_amd.scripts.train.Trainer` calls `forward_backward` directly and applies
+    `clava_adamw_ema_f32` to one flat parameter buffer (optionally after an RCCL all-reduce of one flat gradient).
+
+Mirrors `mixed_loss` (`tab_ddpm/gaussian_multinomial_diffsuion.py:636-675`) and autograd's backward through
+`MLPDiffusion.forward` (`tab_ddpm/modules.py:451-460`).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import c_float, c_int, check, lib, ptr, require_cuda, stream_ptr
+from .tab_ddpm.modules import timestep_embedding
+
+c_ll = ctypes.c_longlong
+GRAD_SPLITS = 8   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
+
+
+def param_list(net):
+    """Parameters of an MLPDiffusion in `net.parameters()` order (the order torch.optim sees, scripts/train.py:17)."""
+    return list(net.parameters())
+
+
+class FlatLayout:
+    """Offsets of every parameter of a denoiser inside one flat float32 buffer."""
+
+    def __init__(self, net):
+        self.names, self.shapes, self.offsets = [], [], []
+        off = 0
+        for name, p in net.named_parameters():
+            self.names.append(name)
+            self.shapes.append(tuple(p.shape))
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned inside the flat buffer
+        self.total = off
+        self.index = {n: i for i, n in enumerate(self.names)}
+
+    def view(self, flat, name):
+        i = self.index[name]
+        n = 1
+        for s in self.shapes[i]:
+            n *= s
+        return flat[self.offsets[i]:self.offsets[i] + n].view(self.shapes[i])
+
+
+def _silu(z):
+    a = torch.empty_like(z)
+    check(lib().clava_silu_f32(ptr(z), ptr(a), c_ll(z.numel()), stream_ptr()), "clava_silu_f32")
+    return a
+
+
+def _silu_backward(z, da):
+    dz = torch.empty_like(z)
+    check(lib().clava_silu_backward_f32(ptr(z), ptr(da), ptr(dz), c_ll(z.numel()), stream_ptr()), "clava_silu_backward_f32")
+    return dz
+
+
+def denoiser_forward(net, x_in, t):
+    """MLPDiffusion forward keeping what the backward needs.  Returns (model_out, saved)."""
+    te = timestep_embedding(t, net.dim_t)
+    w0, b0 = net.time_embed[0].weight.detach(), net.time_embed[0].bias.detach()
+    w2, b2 = net.time_embed[2].weight.detach(), net.time_embed[2].bias.detach()
+    z1 = ops.linear(te, w0, b0)
+    a1 = _silu(z1)
+    emb = ops.linear(a1, w2, b2)
+    ws, bs, acts = net.stack()
+    h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)            # proj(x) + emb (modules.py:459)
+    hs = [h]
+    for l in range(1, len(ws)):
+        h = ops.linear(h, ws[l].detach(), bs[l].detach(), act="relu" if l < len(ws) - 1 else None)
+        hs.append(h)
+    return hs[-1], (x_in, te, z1, a1, hs)
+
+
+def denoiser_backward(net, saved, d_out, layout, slabs, splits=GRAD_SPLITS, want_dx=False):
+    """Backward through the denoiser: fills `slabs` [splits, layout.total] with partial parameter gradients
+    (weight slabs from clava_gemm_wgrad_f32, bias slabs from clava_colsum_slabs_f32); returns dx or None."""
+    x_in, te, z1, a1, hs = saved
+    total = layout.total
+    M = d_out.shape[0]
+
+    def param_grads(prefix, dy, inp):
+        wi = layout.index[prefix + ".weight"]
+        n_out, k_in = layout.shapes[wi]
+        wslab = slabs[:, layout.offsets[wi]:]
+        ops.linear_wgrad(dy, inp, splits=splits, out=wslab, slab_stride=total)
+        bi = layout.index[prefix + ".bias"]
+        bslab = slabs[:, layout.offsets[bi]:]
+        check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(M), c_int(n_out), c_int(splits), ptr(bslab),
+                                           c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
+
+    n_blocks = len(net.mlp.blocks)
+    names = ["proj"] + [f"mlp.blocks.{i}.linear" for i in range(n_blocks)] + ["mlp.head"]
+    ws, _, _ = net.stack()
+    g = d_out                                   # gradient w.r.t. the pre-activation of layer l (head has no activation)
+    for l in range(len(ws) - 1, 0, -1):
+        param_grads(names[l], g, hs[l - 1])
+        # input gradient, with ReLU' of the previous block folded in (layer 0 = proj has no activation)
+        g = ops.linear_dgrad(g, ws[l].detach(), act_out=hs[l - 1] if l - 1 >= 1 else None, slope=0.0)
+    param_grads("proj", g, x_in)
+    # time-embedding branch: emb was added to proj's output, so d emb = g
+    param_grads("time_embed.2", g, a1)
+    d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
+    d_z1 = _silu_backward(z1, d_a1)
+    param_grads("time_embed.0", d_z1, te)
+    if want_dx:
+        return ops.linear_dgrad(g, ws[0].detach())
+    return None
+
+
+def reduce_slabs(slabs, scale=1.0, out=None):
+    """Flat gradient = scale * sum over slabs (fixed order)."""
+    S, total = slabs.shape
+    if out is None:
+        out = torch.empty(total, device=slabs.device, dtype=torch.float32)
+    check(lib().clava_slab_reduce_f32(ptr(slabs), c_int(S), c_ll(total), c_ll(total), c_float(scale), ptr(out), stream_ptr()),
+          "clava_slab_reduce_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- losses
+def _device_sum(v, scale):
+    out = torch.empty((), device=v.device, dtype=torch.float32)
+    check(lib().clava_sum_f32(ptr(v), c_ll(v.numel()), c_float(scale), ptr(out), stream_ptr()), "clava_sum_f32")
+    return out
+
+
+def noised_input(diffusion, x, t, noise, uniforms, seed):
+    """q-sample both halves straight into the denoiser input buffer.  Returns (x_in, noise, idx0, idxt)."""
+    dev = x.device
+    B = x.shape[0]
+    n = diffusion.num_numerical_features
+    D = n + diffusion._sum_k
+    x_in = torch.empty((B, D), device=dev, dtype=torch.float32)
+    sched = diffusion._c_schedule()
+    idx0 = idxt = None
+    if n > 0:
+        x_num = x[:, :n].float().contiguous()
+        check(lib().clava_gauss_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(x_num), ptr(noise), ptr(t), ptr(x_in),
+                                            c_int(D), stream_ptr()), "clava_gauss_qsample_f32")
+    if diffusion.has_cat:
+        m, sk = diffusion._m, diffusion._sum_k
+        idx0 = x[:, n:].to(torch.int32).contiguous()           # `x_cat.long()` of :650
+        idxt = torch.empty_like(idx0)
+        xin_cat = x_in[:, n:]
+        check(lib().clava_multinomial_step_f32(ctypes.byref(sched), c_int(2), c_int(B), c_int(m), c_int(sk),
+                                               ptr(diffusion._offsets_i32), ptr(diffusion._log_k), None, c_int(0), ptr(idx0), ptr(idxt),
+                                               ptr(uniforms), c_int(sk), ptr(xin_cat), c_int(D), None, c_int(0), ptr(t), c_int(0),
+                                               _lib.c_u64(seed), _lib.c_u64(0), ctypes.c_uint(0), stream_ptr()),
+              "clava_multinomial_step_f32(q_sample)")
+    return x_in, idx0, idxt
+
+
+def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
+    """Both loss means (0-dim device tensors, or None for an absent half) and d(loss_multi + loss_gauss)/d(model_out)."""
+    B, D = model_out.shape
+    n = diffusion.num_numerical_features
+    dev = model_out.device
+    d_out = torch.empty((B, D), device=dev, dtype=torch.float32)
+    loss_multi = loss_gauss = None
+    if n > 0:
+        if diffusion.gaussian_loss_type != "mse":
+            raise NotImplementedError("gaussian_loss_type='kl' is not implemented on the HIP path (every config uses 'mse')")
+        rows = torch.empty(B, device=dev, dtype=torch.float32)
+        check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(D), ptr(noise), ptr(rows), ptr(d_out), c_int(D),
+                                             stream_ptr()), "clava_gauss_mse_loss_f32")
+        loss_gauss = _device_sum(rows, 1.0 / B)
+    if diffusion.has_cat:
+        if diffusion.multinomial_loss_type != "vb_stochastic" or diffusion.parametrization != "x0":
+            raise NotImplementedError("only multinomial_loss_type='vb_stochastic' with parametrization='x0' is implemented")
+        m, sk = diffusion._m, diffusion._sum_k
+        terms = torch.empty((B, m), device=dev, dtype=torch.float32)
+        sched = diffusion._c_schedule()
+        pt = torch.tensor(1.0, dtype=torch.float32) / diffusion.num_timesteps        # ones_like(t).float() / T  (:592)
+        check(lib().clava_multinomial_loss_f32(ctypes.byref(sched), c_int(B), c_int(m), c_int(sk), ptr(diffusion._offsets_i32),
+                                               ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(D), ptr(idx0), ptr(idxt), ptr(t),
+                                               c_float(float(pt)), ptr(terms), ptr(d_out[:, n:]), c_int(D), stream_ptr()),
+              "clava_multinomial_loss_f32")
+        loss_multi = _device_sum(terms, 1.0 / (m * B))
+    return loss_multi, loss_gauss, d_out
+
+
+class _MixedLossFn(torch.autograd.Function):
+    """(loss_multi, loss_gauss) from the denoiser output; backward hands the fused gradient back to autograd."""
+
+    @staticmethod
+    def forward(ctx, model_out, diffusion, noise, idx0, idxt, t):
+        lm, lg, d_out = loss_and_grad(diffusion, model_out.detach().contiguous(), noise, idx0, idxt, t)
+        ctx.save_for_backward(d_out)
+        ctx.n = diffusion.num_numerical_features
+        zero = torch.zeros((), device=model_out.device)
+        return (lm if lm is not None else zero), (lg if lg is not None else zero)
+
+    @staticmethod
+    def backward(ctx, g_multi, g_gauss):
+        (d_out,) = ctx.saved_tensors
+        d = d_out
+        if float(g_multi) != 1.0 or float(g_gauss) != 1.0:      # rare: the training loop sums the two losses unweighted
+            d = d_out.clone()
+            d[:, :ctx.n] *= g_gauss
+            d[:, ctx.n:] *= g_multi
+        return d, None, None, None, None, None
+
+
+class _DenoiserFn(torch.autograd.Function):
+    """MLPDiffusion.forward under autograd: backward produces every parameter gradient with the HIP GEMMs."""
+
+    @staticmethod
+    def forward(ctx, net, x_in, t, *params):
+        out, saved = denoiser_forward(net, x_in.detach().float().contiguous(), t)
+        ctx.net, ctx.saved = net, saved
+        ctx.want_dx = x_in.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net = ctx.net
+        layout = FlatLayout(net)
+        slabs = torch.empty((GRAD_SPLITS, layout.total), device=d_out.device, dtype=torch.float32)
+        dx = denoiser_backward(net, ctx.saved, d_out.contiguous(), layout, slabs, want_dx=ctx.want_dx)
+        flat = reduce_slabs(slabs)
+        grads = [layout.view(flat, name) for name in layout.names]
+        return (None, dx, None, *grads)
+
+
+def mlp_diffusion_autograd(net, x, timesteps, y=None):
+    if getattr(net, "is_y_cond", "none") == "embedding" and y is not None:
+        raise NotImplementedError("is_y_cond='embedding' has no HIP training path (ClavaDDPM trains with 'none')")
+    require_cuda(x, timesteps)
+    return _DenoiserFn.apply(net, x, timesteps.long().contiguous(), *param_list(net))
+
+
+def draw(diffusion, x, draws):
+    """Timesteps, Gaussian noise, categorical uniforms and the Philox seed of one training step.
+    Injected (`draws`) for parity tests; otherwise t and noise come from torch's device generator (the reference's
+    `torch.randint` / `torch.randn_like`, :590, :647) and the categorical uniforms from the in-kernel generator."""
+    B = x.shape[0]
+    n = diffusion.num_numerical_features
+    dev = x.device
+    if draws is not None:
+        t = draws["t"].to(dev).long().contiguous()
+        noise = draws["noise"].to(dev).float().contiguous() if n > 0 else None
+        u = draws["u"].to(dev).float().contiguous() if diffusion.has_cat else None
+        return t, noise, u, 0
+    t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev).long()
+    noise = torch.randn((B, n), device=dev, dtype=torch.float32) if n > 0 else None
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if diffusion.has_cat else 0
+    return t, noise, None, seed
+
+
+def mixed_loss(diffusion, x, out_dict, draws=None):
+    """Compat path of `mixed_loss` (`:636-675`): differentiable (loss_multi.mean(), loss_gauss.mean())."""
+    require_cuda(x)
+    t, noise, u, seed = draw(diffusion, x, draws)
+    x_in, idx0, idxt = noised_input(diffusion, x, t, noise, u, seed)
+    model_out = diffusion._denoise_fn(x_in, t, **out_dict)
+    lm, lg = _MixedLossFn.apply(model_out, diffusion, noise, idx0, idxt, t)
+    # an absent half is a CPU `zeros((1,)).mean()` in the reference (:664-665); keep the 0-dim shape, stay on the device
+    return lm, lg

@@ -63,11 +63,11 @@ int clava_gemm_dgrad_f32(const float* dy, int lddy, const float* w, int ldw, con
                          float slope, const float* col_scale, float alpha, float* dx, int lddx, int M, int N_out,
                          int K_in, void* stream);
 
-/* dw_slabs[s][N_out,K_in] = partial_s( dy[M,N_out]^T . x[M,K_in] ), s < splits: the batch dimension is cut into
+/* dw_slabs[s*slab_stride + n*lddw + k] = partial_s( dy[M,N_out]^T . x[M,K_in] ), s < splits: the batch dimension is cut into
  * `splits` ranges so that small weight matrices still fill the chip; the caller sums the slabs in a fixed order
  * (clava_adamw_ema_f32 does).  Replaces the weight-gradient half of loss.backward() (scripts/train.py:37). */
-int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, float* dw_slabs, int lddw, int M,
-                         int N_out, int K_in, int splits, void* stream);
+int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, float* dw_slabs, int lddw,
+                         long long slab_stride, int M, int N_out, int K_in, int splits, void* stream);
 
 /* ---- schedule tables ---------------------------------------------------------------------------------------
  * Device-resident tables of length T, built by the host exactly as GaussianMultinomialDiffusion.__init__ builds
@@ -195,6 +195,49 @@ long long clava_chain_workspace_floats(const clava_chain* c, int B);
 /* x [B,n_num] float64 (in: x at t_start, out: x after n_steps steps), idx [B,m] int32 likewise; ws = device workspace. */
 int clava_sample_chain_f32(const clava_chain* c, int B, double* x, int* idx, float* ws, long long ws_floats,
                            void* stream);
+
+/* ---- training step ------------------------------------------------------------------------------------------
+ * Gaussian 'mse' loss and its gradient: loss_rows[b] = mean_c (noise - model_out)^2, d_out[b,c] = 2 (model_out -
+ * noise) / (n_num * B), i.e. the gradient of loss_rows.mean().  Replaces _gaussian_loss (:282-300, 'mse' branch) and
+ * its autograd backward. */
+int clava_gauss_mse_loss_f32(int B, int n_num, const float* model_out, int ld_out, const float* noise, float* loss_rows,
+                             float* d_out, int ld_d, void* stream);
+
+/* Multinomial variational loss per (row, feature) block and its gradient w.r.t. the categorical logits:
+ *   loss_terms[b,f] = (t_b == 0 ? decoder NLL : KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t))) / pt + KL prior
+ *   d_logits       = gradient of mean_b( sum_f loss_terms[b,f] / m )
+ * idx0 / idxt are the clean and noised category indices [B,m] (int32), pt = 1/T as float32.  Replaces
+ * _multinomial_loss 'vb_stochastic' = compute_Lt + kl_prior (:544-572, :597-607), multinomial_kl (:387-389),
+ * log_categorical (tab_ddpm/utils.py:124-125) and their autograd backward. */
+int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int sumK, const int* offsets, const float* log_k,
+                               const float* logits, int ld_logits, const int* idx0, const int* idxt,
+                               const long long* t_rows, float pt, float* loss_terms, float* d_logits, int ld_d,
+                               void* stream);
+
+/* out[0] = scale * sum(v[0..n)), fixed summation order (the .mean() of the loss terms, :675). */
+int clava_sum_f32(const float* v, long long n, float scale, float* out, void* stream);
+
+/* db_slabs[s][0..N) = column sums of dy over the s-th of `splits` batch ranges (bias gradients; same slab scheme as
+ * clava_gemm_wgrad_f32). */
+int clava_colsum_slabs_f32(const float* dy, int lddy, int M, int N, int splits, float* db_slabs, long long slab_stride,
+                           void* stream);
+
+/* out[i] = scale * sum_s slabs[s*slab_stride + i], fixed order (flat gradient for autograd / the RCCL all-reduce). */
+int clava_slab_reduce_f32(const float* slabs, int splits, long long slab_stride, long long n, float scale, float* out,
+                          void* stream);
+
+/* SiLU and its backward for the time-embedding branch (nn.SiLU in time_embed, tab_ddpm/modules.py:445-449):
+ * a = z * sigmoid(z);  dz = da * sigmoid(z) * (1 + z * (1 - sigmoid(z))). */
+int clava_silu_f32(const float* z, float* a, long long n, void* stream);
+int clava_silu_backward_f32(const float* z, const float* da, float* dz, long long n, void* stream);
+
+/* Fused optimizer step over n contiguous parameters: gradient = grad_scale * sum_s grad_slabs[s*slab_stride + i]
+ * (fixed order), then torch.optim.AdamW's update (decoupled decay, bias-corrected moments; scripts/train.py:17, 38)
+ * and, if ema != NULL, update_ema: ema = ema*ema_rate + param*(1-ema_rate) (scripts/utils_train.py:20-29).
+ * `step` is the 1-based optimizer step count. */
+int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg_sq, const float* grad_slabs, int splits,
+                        long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, long long step, double ema_rate, void* stream);
 
 #ifdef __cplusplus
 }

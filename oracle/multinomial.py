@@ -76,9 +76,12 @@ def q_posterior_unnormed(tb, log_x0, log_xt, t, K):
     return ev + q_pred_one_timestep(tb, log_xt, t, K)
 
 
-def q_posterior(tb, log_x0, log_xt, t, K):
-    """`q_posterior` (`:426-455`)."""
+def q_posterior(tb, log_x0, log_xt, t, K, exact=False):
+    """`q_posterior` (`:426-455`).  `exact=True` swaps the reference's cancellation-prone normaliser for a direct
+    per-block float64 log-sum-exp (see `sliced_logsumexp_exact`): what the HIP kernels compute."""
     u = q_posterior_unnormed(tb, log_x0, log_xt, t, K)
+    if exact:
+        return u - sliced_logsumexp_exact(u, K).to(u.dtype)
     return u - sliced_logsumexp(u, K)
 
 
@@ -99,9 +102,9 @@ def p_pred_exact_norm(tb, model_out, log_xt, t, K):
     return u.double() - sliced_logsumexp_exact(u, K)
 
 
-def p_pred(tb, model_out, log_xt, t, K):
+def p_pred(tb, model_out, log_xt, t, K, exact=False):
     """`p_pred` (`:457-466`), 'x0' parametrisation."""
-    return q_posterior(tb, predict_start(model_out, K), log_xt, t, K)
+    return q_posterior(tb, predict_start(model_out, K), log_xt, t, K, exact)
 
 
 def sample_categorical(logits, uniforms, K):
@@ -139,19 +142,19 @@ def kl_prior(tb, log_x0, K, T):
     return multinomial_kl(lq, lh)
 
 
-def compute_Lt(tb, model_out, log_x0, log_xt, t, K):
+def compute_Lt(tb, model_out, log_x0, log_xt, t, K, exact=False):
     """`compute_Lt` (`:555-572`)."""
-    true = q_posterior(tb, log_x0, log_xt, t, K)
-    model = p_pred(tb, model_out, log_xt, t, K)
+    true = q_posterior(tb, log_x0, log_xt, t, K, exact)
+    model = p_pred(tb, model_out, log_xt, t, K, exact)
     kl = multinomial_kl(true, model)
     nll = -(log_x0.exp() * model).sum(dim=1)
     first = (t == 0).float()
     return first * nll + (1.0 - first) * kl
 
 
-def multinomial_loss(tb, model_out, log_x0, log_xt, t, pt, K, T):
+def multinomial_loss(tb, model_out, log_x0, log_xt, t, pt, K, T, exact=False):
     """`_multinomial_loss` 'vb_stochastic' (`:597-607`)."""
-    return compute_Lt(tb, model_out, log_x0, log_xt, t, K) / pt + kl_prior(tb, log_x0, K, T)
+    return compute_Lt(tb, model_out, log_x0, log_xt, t, K, exact) / pt + kl_prior(tb, log_x0, K, T)
 
 
 def onehot_to_index(ohe, K):

@@ -21,7 +21,7 @@ def adamw_reference_step(w, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
     w.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def run_loop(tb, T, p, batches, draws, n_num, K, lr, weight_decay, steps, ema_rate=0.999):
+def run_loop(tb, T, p, batches, draws, n_num, K, lr, weight_decay, steps, ema_rate=0.999, exact_norm=False):
     """Runs `len(batches)` iterations of a `steps`-long schedule.
 
     `p` is a dict of leaf tensors (updated in place); `draws[i]` = dict(t, noise, u).
@@ -35,7 +35,7 @@ def run_loop(tb, T, p, batches, draws, n_num, K, lr, weight_decay, steps, ema_ra
     hist = []
     for step, (x, d) in enumerate(zip(batches, draws)):
         opt.zero_grad()
-        lm, lg = mixed_loss(tb, T, p, x, n_num, K, d["t"], d["noise"], d.get("u"))
+        lm, lg = mixed_loss(tb, T, p, x, n_num, K, d["t"], d["noise"], d.get("u"), exact_norm=exact_norm)
         (lm + lg).backward()
         opt.step()
         for g in opt.param_groups:                     # _anneal_lr, applied after the step (:24-28, :53)
