@@ -1,0 +1,204 @@
+// Diagonal-covariance Gaussian-mixture E-step in float64 on the gfx950 matrix cores.
+//
+// Replaces the arithmetic behind `GaussianMixture(covariance_type='diag').fit(X).predict(X)` at
+// pipeline_modules.py:268-277, i.e. scikit-learn's `_estimate_log_gaussian_prob` ('diag' branch: two N x d x k
+// float64 products), `_estimate_weighted_log_prob`, `_estimate_log_prob_resp` (log-sum-exp over components) and
+// `predict` (arg-max), called once per EM iteration (<= 100) plus the final E-step and predict.
+//
+//   lp[n,c]  = sum_j mu^2 P - 2 * X[n,:] . (mu P)[c,:] + X[n,:]^2 . P[c,:]            (P = prec_chol^2)
+//   wlp[n,c] = -0.5 * (d ln 2pi + lp) + sum_j ln prec_chol[c,j] + ln w[c]
+//   log_prob_norm[n] = logsumexp_c wlp ;  log_resp = wlp - log_prob_norm ;  label = argmax_c wlp
+//
+// Structure: a 256-thread workgroup owns 64 consecutive rows (one 16-row MFMA tile per wave); the feature axis is
+// walked in chunks of 32 columns: the X chunk (coalesced 16-B loads of whole row segments) and the two k x 32 table
+// chunks are staged in LDS, then v_mfma_f64_16x16x4_f64 accumulates both products for up to four 16-component column
+// tiles (k <= 64).  X is read from HBM exactly once; the kernel is HBM-bound for k*d small and f64-MFMA-bound
+// otherwise.  The two products keep separate accumulators and are combined in scikit-learn's order.
+#include "common.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DC = 32;           // feature columns per chunk
+constexpr int LDT = DC + 1;      // LDS row stride in doubles
+constexpr int ROWS = 64;         // rows per workgroup
+constexpr int KMAX = 64;         // components supported
+
+struct GmmArgs {
+    const double* X; long long ldx; long long N; int d, k;
+    const double* mp;        // [k, d] means * precisions
+    const double* P;         // [k, d] precisions = prec_chol^2
+    const double* s_mu2p;    // [k] sum_j means^2 * precisions
+    const double* logdet;    // [k] sum_j log prec_chol
+    const double* logw;      // [k] log weights
+    double dln2pi;           // d * log(2 pi)
+    double* log_prob_norm;   // [N]
+    double* log_resp;        // [N, k] or null
+    int* labels;             // [N] or null
+};
+
+// tables from the mixture parameters (k*d elements: negligible work, one workgroup per component)
+__global__ void __launch_bounds__(256) gmm_prep_kernel(const double* __restrict__ means, const double* __restrict__ pc,
+                                                       const double* __restrict__ w, int k, int d, double* __restrict__ mp,
+                                                       double* __restrict__ P, double* __restrict__ s_mu2p,
+                                                       double* __restrict__ logdet, double* __restrict__ logw) {
+    const int c = blockIdx.x;
+    __shared__ double part[2][256];
+    double a = 0.0, b = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const double m = means[(size_t)c * d + j], q = pc[(size_t)c * d + j];
+        const double p = q * q;
+        P[(size_t)c * d + j] = p;
+        mp[(size_t)c * d + j] = m * p;
+        a += (m * m) * p;
+        b += log(q);
+    }
+    part[0][threadIdx.x] = a; part[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { part[0][threadIdx.x] += part[0][threadIdx.x + s]; part[1][threadIdx.x] += part[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { s_mu2p[c] = part[0][0]; logdet[c] = part[1][0]; logw[c] = log(w[c]); }
+}
+
+template <int CT>   // number of 16-component column tiles (1..4)
+__global__ void __launch_bounds__(256) gmm_estep_kernel(GmmArgs g) {
+    __shared__ double Xs[ROWS * LDT];
+    __shared__ double Ms[CT * 16 * LDT];
+    __shared__ double Ps[CT * 16 * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    for (long long row0 = (long long)blockIdx.x * ROWS; row0 < g.N; row0 += (long long)gridDim.x * ROWS) {
+        f64x4 acc1[CT], acc2[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { acc1[ct] = {0.0, 0.0, 0.0, 0.0}; acc2[ct] = {0.0, 0.0, 0.0, 0.0}; }
+        for (int j0 = 0; j0 < g.d; j0 += DC) {
+            __syncthreads();     // previous chunk fully consumed
+            // stage the X chunk: thread -> (row, column pair); 16 threads cover one 32-column row segment
+            for (int s = tid; s < ROWS * (DC / 2); s += 256) {
+                const int rr = s / (DC / 2), cc = (s % (DC / 2)) * 2;
+                const long long row = row0 + rr;
+                double v0 = 0.0, v1 = 0.0;
+                if (row < g.N) {
+                    const double* p = g.X + row * g.ldx + j0 + cc;
+                    if (j0 + cc < g.d) v0 = p[0];
+                    if (j0 + cc + 1 < g.d) v1 = p[1];
+                }
+                Xs[rr * LDT + cc] = v0;
+                Xs[rr * LDT + cc + 1] = v1;
+            }
+            for (int s = tid; s < CT * 16 * DC; s += 256) {
+                const int c = s / DC, cc = s % DC;
+                const bool ok = c < g.k && j0 + cc < g.d;
+                Ms[c * LDT + cc] = ok ? g.mp[(size_t)c * g.d + j0 + cc] : 0.0;
+                Ps[c * LDT + cc] = ok ? g.P[(size_t)c * g.d + j0 + cc] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < DC / 4; ++ks) {
+                // A operand of v_mfma_f64_16x16x4_f64: lane holds A[row = lane & 15][k = lane >> 4]
+                const double a1 = Xs[(wave * 16 + r) * LDT + ks * 4 + q];
+                const double a2 = a1 * a1;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const double b1 = Ms[(ct * 16 + r) * LDT + ks * 4 + q];   // B[k = lane >> 4][col = lane & 15]
+                    const double b2 = Ps[(ct * 16 + r) * LDT + ks * 4 + q];
+                    acc1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1[ct], 0, 0, 0);
+                    acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc2[ct], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue.  f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long long row = row0 + wave * 16 + q + 4 * reg;
+            double wlp[CT];
+            double mx = -INFINITY;
+            int arg = 0x7fffffff;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + r;
+                if (c < g.k) {
+                    const double lp = (g.s_mu2p[c] - 2.0 * acc1[ct][reg]) + acc2[ct][reg];
+                    wlp[ct] = ((-0.5 * (g.dln2pi + lp)) + g.logdet[c]) + g.logw[c];
+                } else {
+                    wlp[ct] = -INFINITY;
+                }
+                if (wlp[ct] > mx) { mx = wlp[ct]; arg = c; }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {       // the 16 lanes of a row group hold the row's components
+                const double om = __shfl_xor(mx, o, 64);
+                const int oa = __shfl_xor(arg, o, 64);
+                if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+            }
+            double sm = 0.0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) sm += (ct * 16 + r < g.k) ? exp(wlp[ct] - mx) : 0.0;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            const double lse = mx + log(sm);
+            if (row < g.N) {
+                if (r == 0) {
+                    g.log_prob_norm[row] = lse;
+                    if (g.labels) g.labels[row] = arg;
+                }
+                if (g.log_resp) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int c = ct * 16 + r;
+                        if (c < g.k) g.log_resp[row * g.k + c] = wlp[ct] - lse;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+long long clava_gmm_workspace_doubles(int k, int d) { return 2LL * k * d + 3LL * k; }
+
+int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int k, const double* weights,
+                        const double* means, const double* precisions_chol, double* workspace, double* log_prob_norm,
+                        double* log_resp, int* labels, void* stream) {
+    CLAVA_CHECK_ARG(X && weights && means && precisions_chol && workspace && log_prob_norm, "gmm_estep: null argument");
+    CLAVA_CHECK_ARG(N > 0 && d > 0 && k > 0 && ldx >= d, "gmm_estep: bad shape N=%lld d=%d k=%d", N, d, k);
+    if (k > KMAX) {
+        clava_set_error("gmm_estep: k=%d components exceeds the supported maximum of %d", k, KMAX);
+        return CLAVA_ERR_LIMIT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    GmmArgs g;
+    g.X = X; g.ldx = ldx; g.N = N; g.d = d; g.k = k;
+    double* w = workspace;
+    double* mp = w;             w += (size_t)k * d;
+    double* P = w;              w += (size_t)k * d;
+    double* s_mu2p = w;         w += k;
+    double* logdet = w;         w += k;
+    double* logw = w;
+    g.mp = mp; g.P = P; g.s_mu2p = s_mu2p; g.logdet = logdet; g.logw = logw;
+    g.dln2pi = (double)d * 1.8378770664093453;     // log(2 pi)
+    g.log_prob_norm = log_prob_norm; g.log_resp = log_resp; g.labels = labels;
+    hipLaunchKernelGGL(gmm_prep_kernel, dim3(k), dim3(256), 0, st, means, precisions_chol, weights, k, d, mp, P, s_mu2p, logdet, logw);
+    CLAVA_CHECK_LAUNCH("clava_gmm_estep_f64(prep)");
+    const long long blocks = (N + ROWS - 1) / ROWS;
+    const int grid = (int)(blocks < 65536 ? blocks : 65536);
+    // algorithmic traffic: X once, log_resp + log_prob_norm (+ labels) once; flops: two N x d x k products
+    ProfScope prof(PROF_GMM, 4.0 * N * d * k, 8.0 * N * (d + (log_resp ? k : 0) + 1) + (labels ? 4.0 * N : 0.0), st);
+    const int ct = (k + 15) / 16;
+    switch (ct) {
+        case 1: hipLaunchKernelGGL((gmm_estep_kernel<1>), dim3(grid), dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gmm_estep_kernel<2>), dim3(grid), dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL((gmm_estep_kernel<3>), dim3(grid), dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((gmm_estep_kernel<4>), dim3(grid), dim3(256), 0, st, g); break;
+    }
+    CLAVA_CHECK_LAUNCH("clava_gmm_estep_f64");
+    return CLAVA_OK;
+}
+
+}  // extern "C"

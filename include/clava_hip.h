@@ -239,6 +239,19 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
                         long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
                         double eps, double weight_decay, long long step, double ema_rate, void* stream);
 
+/* ---- GMM E-step (parent-child clustering) ----------------------------------------------------------------
+ * Diagonal-covariance mixture E-step in float64 for X[N,d] (row-major, leading dimension ldx) and k <= 64 components:
+ *   log_prob_norm[N], log_resp[N,k] (may be NULL), labels[N] = argmax_c weighted log-probability (may be NULL).
+ * Replaces the scikit-learn arithmetic behind GaussianMixture(covariance_type='diag').fit / .predict at
+ * pipeline_modules.py:268-277: sklearn/mixture/_gaussian_mixture.py `_estimate_log_gaussian_prob` ('diag' branch)
+ * and _base.py `_estimate_weighted_log_prob`, `_estimate_log_prob_resp`, `predict` (scikit-learn 1.4.1.post1 pinned
+ * upstream, requirements.txt:199).  weights[k], means[k,d], precisions_chol[k,d] are device arrays; workspace holds
+ * clava_gmm_workspace_doubles(k, d) doubles.  Returns -3 when k exceeds 64. */
+long long clava_gmm_workspace_doubles(int k, int d);
+int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int k, const double* weights,
+                        const double* means, const double* precisions_chol, double* workspace, double* log_prob_norm,
+                        double* log_resp, int* labels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
