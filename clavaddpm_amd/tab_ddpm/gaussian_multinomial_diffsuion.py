@@ -252,6 +252,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return keep  # caller keeps these alive until it synchronises
 
     def _initial_state(self, b, noise, seed, row_offset):
+        require_cuda(self.log_alpha)          # no CPU path: fail before anything is computed
         dev = self._device()
         n = self.num_numerical_features
         if noise is not None:

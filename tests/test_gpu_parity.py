@@ -126,3 +126,38 @@ def test_g7_classifier_and_cond_grad(tag):
     grad = make_cond_fn(clf, 1.5)(x, t, y=y)
     assert grad.dtype == torch.float32
     assert relerr(grad.cpu(), g[f"{tag}_grad"]) < 1e-4
+
+
+def test_sharded_sampling_is_invariant_to_the_number_of_ranks():
+    """Counter-based noise keyed by the global row: 1 rank and 3 simulated ranks produce the same table, bit for bit."""
+    from clavaddpm_amd import parallel
+    g = golden("g5_chain_cond.npz")
+    T, n_num, C = int(g["T"]), int(g["n_num"]), int(g["C"])
+    net = make_mlp(n_num, [64, 64], sub(g, "p:"))
+    d = make_diffusion([0], n_num, net, T)
+    clf = _classifier(g, "c:", n_num, C, g["hidden"].tolist())
+    cf = make_cond_fn(clf, 1.0)
+    ys = torch.randint(0, C, (301,), generator=torch.Generator().manual_seed(1))
+    full, _ = parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=128, seed=77, rank=0, world=1, gather=False)
+    parts = [parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=50, seed=77, rank=r, world=3, gather=False)[0] for r in range(3)]
+    assert full.shape == (301, n_num) and torch.isfinite(full).all()
+    assert torch.equal(torch.cat(parts), full)
+    other, _ = parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=128, seed=78, rank=0, world=1, gather=False)
+    assert not torch.equal(other, full)
+
+
+def test_sample_all_unconditional_mixed_properties():
+    """sample_all: shapes, dtypes, category ranges, NaN policy and truncation to num_samples (reference :1072-1099)."""
+    K, n_num = [3, 5, 2], 4
+    g = golden("g5_chain_mixed.npz")
+    net = make_mlp(n_num + sum(K), [64, 64], sub(g, "p:"))
+    d = make_diffusion(K, n_num, net, 50)
+    x, y = d.sample_all(150, 64, torch.ones(1), seed=5)
+    assert x.shape == (150, n_num + len(K)) and x.dtype == torch.float64 and y.shape == (150,)
+    cats = x[:, n_num:]
+    assert torch.equal(cats, cats.round()) and bool((cats >= 0).all())
+    assert all(int(cats[:, f].max()) < K[f] for f in range(len(K)))
+    # every class of the 2-class feature shows up among 150 rows (the chain does not collapse)
+    assert set(cats[:, 2].long().tolist()) == {0, 1}
+    x2, _ = d.sample_all(150, 64, torch.ones(1), seed=5)
+    assert torch.equal(x, x2)                                           # same seed, same table

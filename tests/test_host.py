@@ -1,0 +1,147 @@
+"""CPU-only checks: C-ABI surface, host-side logic of the drop-in classes, sharding helpers (gloo, world_size 2)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+from clavaddpm_amd import _lib, parallel
+from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+from clavaddpm_amd.tab_ddpm.schedule import build_tables
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.clava_version() == 100
+    assert L.clava_device_count() >= 0            # host-only probe; no compute call without a GPU
+
+
+def test_header_cites_reference_for_every_entry_point():
+    text = open(os.path.join(ROOT, "include", "clava_hip.h")).read()
+    assert "tab_ddpm/gaussian_multinomial_diffsuion.py" in text and "pipeline_utils.py" in text and "scripts/train.py" in text
+    assert 'extern "C"' in text and "at::Tensor" not in text and "torch::" not in text and "#include <torch" not in text
+
+
+def test_product_schedule_tables_match_reference_golden():
+    g = golden("g1_schedule.npz")
+    for sched in ("cosine", "linear"):
+        for T in (50, 1000, 2000):
+            f32, f64 = build_tables(sched, T)
+            for k, v in f32.items():
+                ref = g[f"{sched}_{T}_{k}"].numpy()
+                assert v.dtype == np.float32
+                np.testing.assert_allclose(v, ref, rtol=1.2e-7, atol=1e-38, err_msg=f"{sched} {T} {k}")
+            np.testing.assert_allclose(f64["posterior_variance"], g[f"{sched}_{T}_posterior_variance_f64"].numpy(), rtol=1e-14)
+            np.testing.assert_allclose(f64["model_variance"], g[f"{sched}_{T}_model_variance_f64"].numpy(), rtol=1e-14)
+            np.testing.assert_allclose(np.log(f64["model_sigma"]) * 2, g[f"{sched}_{T}_model_log_variance_f64"].numpy(), rtol=1e-12)
+
+
+def _small(K=(3, 5, 2), n_num=4):
+    d_in = n_num + (sum(K) if K[0] else 0)
+    net = MLPDiffusion(d_in, 0, "none", {"d_layers": [64, 64], "dropout": 0.0})
+    return net, GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=50)
+
+
+def test_constructor_attributes_and_state_dict_layout():
+    from weights import mlp_shapes
+    net, d = _small()
+    assert list(net.state_dict().keys()) == list(mlp_shapes(14, [64, 64]).keys())
+    for k, shape in mlp_shapes(14, [64, 64]).items():
+        assert tuple(net.state_dict()[k].shape) == tuple(shape)
+    ref_buffers = ["alphas", "log_alpha", "log_1_min_alpha", "log_1_min_cumprod_alpha", "log_cumprod_alpha", "alphas_cumprod",
+                   "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                   "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "Lt_history", "Lt_count"]
+    sd = [k for k in d.state_dict().keys() if not k.startswith("_denoise_fn.")]
+    assert sd == ref_buffers                                  # the HIP-only tables are non-persistent
+    assert d.num_timesteps == 50 and d._denoise_fn is net
+    assert d.offsets.tolist() == [0, 3, 8, 10] and d.num_classes_expanded.tolist() == [3] * 3 + [5] * 5 + [2] * 2
+    assert d.posterior_variance.dtype == torch.float64 and not d.posterior_variance.is_cuda
+    rt = {"d_layers": [8], "dropout": 0.0}
+    MLPDiffusion(3, 0, "none", rt)
+    assert rt["d_in"] == 128 and rt["d_out"] == 3            # the reference mutates the caller's dict (modules.py:434-435)
+    _, d0 = _small(K=(0,))
+    assert not d0.has_cat and d0._m == 0 and d0._sum_k == 0
+
+
+def test_diffusion_pickles_without_library_handles():
+    net, d = _small()
+    d2 = pickle.loads(pickle.dumps(d))
+    assert torch.equal(d2.log_alpha, d.log_alpha) and torch.equal(d2._model_sigma, d._model_sigma)
+    for a, b in zip(d.parameters(), d2.parameters()):
+        assert torch.equal(a, b)
+
+
+def test_no_cpu_fallback_the_product_path_fails_loudly():
+    net, d = _small(K=(0,), n_num=4)
+    with pytest.raises(_lib.ClavaHipError):
+        net(torch.zeros(2, 4), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(_lib.ClavaHipError):
+        d.sample(2, torch.ones(1))
+    with pytest.raises(_lib.ClavaHipError):
+        d.mixed_loss(torch.zeros(2, 4), {"y": torch.zeros(2, dtype=torch.long)})
+    with pytest.raises(_lib.ClavaHipError):
+        d.gaussian_q_sample(torch.zeros(2, 4), torch.zeros(2, dtype=torch.long))
+
+
+def test_product_never_imports_the_oracle():
+    import re
+    pkg = os.path.join(ROOT, "clavaddpm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_row_slices_and_batches_partition_the_rows():
+    for n in (0, 1, 7, 20000, 10_000_019):
+        for world in (1, 2, 3, 8):
+            cuts = [parallel.row_slice(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+    assert parallel.plan_batches(5, 5, 10) == []
+    assert parallel.plan_batches(3, 26, 10) == [(3, 13), (13, 23), (23, 26)]       # short last batch, like the reference loop
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 11
+        a, b = parallel.row_slice(n, rank, world)
+        local = torch.arange(a, b, dtype=torch.float64).reshape(-1, 1) * torch.ones(1, 3, dtype=torch.float64)
+        full = parallel.gather_rows(local)
+        empty = parallel.gather_rows(torch.zeros((0 if rank else 2, 3), dtype=torch.float64))
+        g = torch.full((5,), float(rank + 1))
+        parallel.allreduce_mean_(g)
+        q.put((rank, full[:, 0].tolist(), tuple(empty.shape), g.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_and_gradient_average_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rows, eshape, g in out:
+        assert rows == [float(i) for i in range(11)]           # rank order, ragged slices (6 + 5)
+        assert eshape == (2, 3)                                # a rank with zero rows still takes part
+        assert g == [1.5] * 5                                  # mean of (1, 2)
