@@ -77,6 +77,42 @@ def cpu_baseline(n_num, n_clusters, T, batch, n_steps, threads):
     return batch / (dt / n_steps * T), dt
 
 
+def train_bench(device, n_num, T, batch, steps, warmup, barrier):
+    """Secondary metric of BASELINE.json: denoiser training steps/s (mixed_loss + backward + AdamW + EMA, batch 4096 per
+    GPU, data-parallel all-reduce of the flat gradient when several ranks run)."""
+    import numpy as np
+    from clavaddpm_amd.scripts.train import Trainer
+    from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+    torch.manual_seed(0)
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(DENOISER_LAYERS), "dropout": 0.0}).to(device).train()
+    diff = GaussianMultinomialDiffusion(np.array([0]), n_num, net, num_timesteps=T, scheduler="cosine",
+                                        device=torch.device(device)).to(device).train()
+    data = torch.randn(8 * batch, n_num)
+    y = torch.zeros(batch, dtype=torch.long)
+
+    def it():
+        i = 0
+        while True:
+            yield data[i * batch:(i + 1) * batch], y
+            i = (i + 1) % 8
+
+    tr = Trainer(diff, it(), lr=6e-4, weight_decay=1e-5, steps=10 ** 9, device=torch.device(device))
+    src = it()
+    for _ in range(warmup):
+        x, yy = next(src)
+        tr._run_step(x, {"y": yy})
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        x, yy = next(src)
+        tr._run_step(x, {"y": yy})
+    barrier()
+    dt = time.perf_counter() - t0
+    flops = batch * 6.0 * (640 * n_num + 4292608)
+    return {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "batch_per_gpu": batch,
+            "steps_timed": steps, "tflops_per_gpu": round(flops * steps / dt / 1e12, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +124,7 @@ def main():
     ap.add_argument("--clusters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--train-steps", type=int, default=100, help="timed training steps for the secondary metric (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +206,15 @@ def main():
                         "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
                         "flops_per_launch": round(fl[0] / launches[0])}
 
+    train = None
+    if args.train_steps > 0:
+        train = train_bench(device, args.n_num, T, 4096, args.train_steps, 10, barrier)
+        if dist is not None:
+            tm = torch.tensor([train["ms_per_step"]], device=device, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            train["ms_per_step"] = round(float(tm.item()), 3)
+            train["steps_per_s"] = round(1e3 / float(tm.item()), 2)
+
     rows = world * B * args.steps
     value = rows / elapsed
     out = {
@@ -180,6 +226,7 @@ def main():
                    "denoiser": DENOISER_LAYERS, "classifier": CLASSIFIER_LAYERS, "guidance_scale": 1.0,
                    "parallelism": f"rows sharded over {world} GPU(s), no data-path collective"},
         "roofline": roofline,
+        "train": train,
     }
     if families:
         out["kernel_families"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
