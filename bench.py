@@ -31,20 +31,41 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2516.8   # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense" = 16 x the f32 matrix rate
 DENOISER_LAYERS = [512, 1024, 1024, 1024, 1024, 512]
 CLASSIFIER_LAYERS = [128, 256, 512, 1024, 512, 256, 128]
 
 
-def build_workload(device, n_num, n_clusters, T):
+def build_workload(device, n_num, n_clusters, T, fit_steps):
+    """Networks of the workload.  The denoiser is fitted for `fit_steps` steps of the library's own Trainer to a synthetic
+    N(0,1) table (the marginals of a quantile-normalised ClavaDDPM table, lib/data.py:217-223): an untrained eps-network
+    makes the reverse chain diverge geometrically (|x| ~ 1e3 after 50 steps), which no real run does and which would
+    push the split-f16 path onto its float32 fallback.  Throughput does not depend on the values otherwise."""
     import numpy as np
     from clavaddpm_amd.pipeline_utils import Classifier, make_cond_fn
+    from clavaddpm_amd.scripts.train import Trainer
     from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
     torch.manual_seed(0)
-    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(DENOISER_LAYERS), "dropout": 0.0}).to(device).eval()
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(DENOISER_LAYERS), "dropout": 0.0}).to(device)
     clf = Classifier(d_in=n_num, d_out=n_clusters, dim_t=128, hidden_sizes=list(CLASSIFIER_LAYERS)).to(device).eval()
     diff = GaussianMultinomialDiffusion(np.array([0]), n_num, net, num_timesteps=T, scheduler="cosine",
-                                        device=torch.device(device)).to(device).eval()
+                                        device=torch.device(device)).to(device)
+    if fit_steps > 0:
+        g = torch.Generator().manual_seed(7)
+        table = torch.randn(64 * 4096, n_num, generator=g)
+        y = torch.zeros(4096, dtype=torch.long)
+
+        def rows():
+            i = 0
+            while True:
+                yield table[i * 4096:(i + 1) * 4096], y
+                i = (i + 1) % 64
+
+        net.train(); diff.train()
+        tr = Trainer(diff, rows(), lr=1e-3, weight_decay=0.0, steps=fit_steps, device=torch.device(device))
+        tr.run_loop()
+    net.eval(); diff.eval()
     return diff, net, clf, make_cond_fn(clf, 1.0)
 
 
@@ -123,8 +144,12 @@ def main():
     ap.add_argument("--n-num", type=int, default=2)
     ap.add_argument("--clusters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--train-steps", type=int, default=100, help="timed training steps for the secondary metric (0 = skip)")
+    ap.add_argument("--fit-steps", type=int, default=600, help="Trainer steps that fit the denoiser to the synthetic table before sampling")
+    ap.add_argument("--gemm", choices=["f16x3", "f32"], default="f16x3",
+                    help="layer kernels of the sampling loop: split-f16 on the f16 matrix cores (float32-level accuracy) or float32-input MFMA")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra chain timed on the float32-input MFMA kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,10 +167,11 @@ def main():
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
-    from clavaddpm_amd import _lib
+    from clavaddpm_amd import _lib, split_nets
     L = _lib.lib()
     T, B = args.timesteps, args.batch
-    diff, net, clf, cond_fn = build_workload(device, args.n_num, args.clusters, T)
+    split_nets.set_gemm_mode(args.gemm)
+    diff, net, clf, cond_fn = build_workload(device, args.n_num, args.clusters, T, args.fit_steps)
     g = torch.Generator().manual_seed(1234 + rank)
     ys = torch.randint(0, args.clusters, (B, 1), generator=g).to(device)
 
@@ -178,6 +204,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(x).all()), "non-finite samples"
+    x_absmax = float(x.abs().max())
 
     roofline = None
     families = {}
@@ -193,18 +220,32 @@ def main():
                 families[L.clava_prof_family_name(f).decode()] = {
                     "launches": launches[f], "avg_us": 1e3 * ms[f] / launches[f], "ms": ms[f],
                     "tflops": fl[f] / ms[f] / 1e9 if ms[f] > 0 else 0.0, "gbps": by[f] / ms[f] / 1e6 if ms[f] > 0 else 0.0}
-        dom = "gemm_f32_nt_128x128"
+        names = [L.clava_prof_family_name(f).decode() for f in range(n_fam)]
+        dom = "gemm_f16x3" if args.gemm == "f16x3" else "gemm_f32_nt_128x128"
         if dom in families:
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            tpath = os.path.join(ROOT, "profiles", "traffic_r01_f16x3.json" if args.gemm == "f16x3" else "traffic_r01.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             f = families[dom]
-            roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<true,true,128,128,true,false> (fp32 v_mfma_f32_32x32x2_f32; the denoiser's layers)",
-                        "achieved": round(f["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(f["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
-                        "flops_per_launch": round(fl[0] / launches[0])}
+            fi = names.index(dom)
+            if args.gemm == "f16x3":
+                # algorithmic FLOPs = 2*M*N*K of the float32 product; the kernel issues 3 f16 MFMAs per product term, so
+                # the matrix cores are busy for 3x that: both fractions are reported, `frac` is the algorithmic one
+                roofline = {"bound": "mfma", "kernel": "gemm_f16x3_kernel<BN,BM,WN> (split-f16: 3 x v_mfma_f32_16x16x32_f16 per float32 product; "
+                                                       "every nn.Linear of the denoiser, the classifier and its input gradient)",
+                            "achieved": round(f["tflops"], 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(f["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
+                            "mfma_issue_frac": round(3.0 * f["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
+                            "vs_f32_matrix_peak": round(f["tflops"] / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
+                            "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
+                            "flops_per_launch": round(fl[fi] / launches[fi])}
+            else:
+                roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel<true,true,128,128,true,false> (fp32 v_mfma_f32_32x32x2_f32; the denoiser's layers)",
+                            "achieved": round(f["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(f["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                            "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
+                            "flops_per_launch": round(fl[fi] / launches[fi])}
 
     train = None
     if args.train_steps > 0:
@@ -215,18 +256,38 @@ def main():
             train["ms_per_step"] = round(float(tm.item()), 3)
             train["steps_per_s"] = round(1e3 / float(tm.item()), 2)
 
+    # the same chain on the float32-input MFMA kernels (one chain, after the timed region): the exact-f32 reference point
+    f32_leg = None
+    if args.gemm == "f16x3" and not args.no_f32_leg:
+        split_nets.set_gemm_mode("f32")
+        x32, keep32 = run_chain(diff, cond_fn, ys, seed + 1 + (args.steps - 1), (world * (args.steps - 1) + rank) * B)
+        barrier()
+        t1 = time.perf_counter()
+        x32b, keep32 = run_chain(diff, cond_fn, ys, seed + 1 + (args.steps - 1), (world * (args.steps - 1) + rank) * B)
+        barrier()
+        dt32 = time.perf_counter() - t1
+        split_nets.set_gemm_mode(args.gemm)
+        dev_rel = float((x - x32).abs().max() / x32.abs().max())
+        f32_leg = {"rows_per_s_per_gpu": round(B / dt32, 1), "ms_per_chain": round(1e3 * dt32, 1),
+                   "max_rel_dev_of_f16x3_samples": dev_rel}
+
     rows = world * B * args.steps
     value = rows / elapsed
     out = {
         "metric": f"synth rows/sec ({T}-step reverse diffusion)", "value": round(value, 1), "unit": "rows/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (split-f16x3 MFMA operands, f32 accumulate, 22-bit significand)" if args.gemm == "f16x3" else "f32",
+        "data": f"synthetic (N(0,1) table; denoiser fitted {args.fit_steps} Trainer steps to it, classifier random-init)",
         "config": {"workload": "movie_lens (movie->rating) cluster-guided sampling, configs/movie_lens.json shapes",
                    "rows_per_gpu_per_step": B, "timesteps": T, "n_num": args.n_num, "clusters": args.clusters,
                    "denoiser": DENOISER_LAYERS, "classifier": CLASSIFIER_LAYERS, "guidance_scale": 1.0,
                    "parallelism": f"rows sharded over {world} GPU(s), no data-path collective"},
         "roofline": roofline,
         "train": train,
+        "f32_mfma_path": f32_leg,
+        "sample_absmax": round(x_absmax, 3),
+        "f16x3_fallbacks": split_nets.fallback_count,
     }
     if families:
         out["kernel_families"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),

@@ -6,6 +6,7 @@
 
 #include "clava_hip.h"
 #include "common.h"
+#include "split.h"
 
 static thread_local char g_err[512] = "";
 
@@ -26,7 +27,7 @@ bool g_prof_open = false;
 const char* const kFamilyNames[PROF_N_FAMILIES] = {
     "gemm_f32_nt_128x128", "gemm_f32_nt_64x64", "gemm_f32_nt_128x128_bn", "gemm_f32_nt_64x64_bn", "gemm_f32_nn_128x128",
     "gemm_f32_nn_64x64", "gemm_f32_tn_128x128", "gemm_f32_tn_64x64", "gauss_step", "multinomial_step", "logsoftmax_select_grad", "misc", "mixed_loss", "adamw_ema",
-    "gmm_estep"};
+    "gmm_estep", "gemm_f16x3"};
 }  // namespace
 
 void clava_prof_begin_(int family, double flops, double bytes, hipStream_t stream) {
@@ -135,6 +136,41 @@ int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, flo
     // dw[N_out, K_in] = dy^T[N_out, M] * x[M, K_in]: contraction over the batch M; both operands MN-major
     return clava_launch_gemm_f32(dy, lddy, false, x, ldx, false, dw_slabs, lddw, N_out, K_in, M, e, splits,
                                  (long)slab_stride, (hipStream_t)stream);
+}
+
+// ---- split-f16 GEMM family (split.h) ------------------------------------------------------------------------------------
+int clava_split_pack_f32(const float* src, long long ld, long long rows, int cols, int shift, void* dst, long long pitch,
+                         int* overflow, void* stream) {
+    return clava_launch_split_pack(src, ld, rows, cols, shift, (char*)dst, pitch, overflow, (hipStream_t)stream);
+}
+
+int clava_split_unpack_f32(const void* src, long long pitch, long long rows, int cols, int shift, float* dst, long long ld,
+                           void* stream) {
+    return clava_launch_split_unpack((const char*)src, pitch, rows, cols, shift, dst, ld, (hipStream_t)stream);
+}
+
+int clava_gemm_f16x3_config_count_(void) { return clava_gemm_f16x3_config_count(); }
+
+int clava_gemm_f16x3(const void* x, long long pitch_x, int shift_x, const void* w, long long pitch_w, int shift_w,
+                     const float* bias, const float* rowadd, int act, const void* act_out, long long pitch_act, float slope,
+                     float alpha, void* y_split, long long pitch_y, int shift_y, float* y_f32, int ldy, int M, int N, int K,
+                     int* overflow, int tile_config, void* stream) {
+    CLAVA_CHECK_ARG(K > 0, "gemm_f16x3: K must be positive");
+    CLAVA_CHECK_ARG(shift_x + shift_w >= -60 && shift_x + shift_w <= 60 && shift_y >= -30 && shift_y <= 30, "gemm_f16x3: shift out of range");
+    SplitGemmArgs g;
+    g.A = (const char*)x; g.W = (const char*)w;
+    g.M = M; g.N = N; g.Kp = (K + 31) & ~31; g.K = K;
+    g.pitchA = pitch_x; g.pitchW = pitch_w;
+    g.bias = bias; g.bias2 = rowadd; g.act = act;
+    g.mask = (const char*)act_out; g.pitchMask = pitch_act; g.mask_slope = slope;
+    g.scale_acc = ldexpf(1.f, -(shift_x + shift_w));
+    g.alpha = alpha;
+    g.scale_out = ldexpf(1.f, shift_y);
+    g.out_split = (char*)y_split; g.pitchOut = pitch_y;
+    g.out_f32 = y_f32; g.ldc = ldy;
+    g.overflow = overflow;
+    g.tiles_m = g.tiles_n = 0;
+    return clava_launch_gemm_f16x3(g, tile_config, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 // time-embedding kernels, and the host-side driver of a whole reverse-diffusion chain.  Everything is enqueued
 // on one stream; nothing synchronises with or copies to the host.
 #include "clava_hip.h"
+#include "split.h"
 #include "step.h"
 
 namespace {
@@ -39,6 +40,12 @@ __global__ void __launch_bounds__(256) timestep_embedding_kernel(const long long
 }
 
 float act_slope(int act) { return act == CLAVA_ACT_LEAKY ? 0.01f : 0.f; }
+
+int max_width_dims(const int* dims, int from, int to) {
+    int w = 0;
+    for (int l = from; l <= to; ++l) w = dims[l] > w ? dims[l] : w;
+    return w;
+}
 
 int check_net(const clava_net* net, const char* who) {
     CLAVA_CHECK_ARG(net && net->n_layers > 0 && net->n_layers <= 64 && net->dims && net->w && net->b && net->act,
@@ -92,6 +99,169 @@ int net_input_grad(const clava_net* net, int M, float* const* outs, const float*
                                        M, net->dims[l], net->dims[l + 1], e, 1, 0, st);
         if (rc) return rc;
         g = grads[l];
+    }
+    return CLAVA_OK;
+}
+
+
+// same gradient, written as split rows (split.h) for the f16 matrix-core input-gradient chain; pad columns get zeros
+__global__ void __launch_bounds__(256) logsoftmax_select_grad_split_kernel(const float* __restrict__ logits, int ld,
+                                                                           const int* __restrict__ y, char* __restrict__ d,
+                                                                           long long pitch, float scale, int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= B) return;
+    const float* l = logits + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, l[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sm = 0.f;
+    for (int c = lane; c < C; c += 64) sm += expf(l[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    const float lse = mx + logf(sm);
+    const int yy = y[row];
+    const int Cp = (C + 31) & ~31;
+    _Float16* out = reinterpret_cast<_Float16*>(d + (size_t)row * pitch);
+    for (int c = lane; c < Cp; c += 64) {
+        const float v = (c < C) ? ((c == yy ? 1.f : 0.f) - expf(l[c] - lse)) * scale : 0.f;
+        const _Float16 hi = (_Float16)v;
+        _Float16* p = out + (c >> 5) * 64 + (c & 31);
+        p[0] = hi;
+        p[32] = (_Float16)(v - (float)hi);
+    }
+}
+
+inline long long split_pitch(int cols) { return 4LL * ((cols + 31) & ~31); }
+
+int check_split_net(const clava_split_net* n, bool need_grad, const char* who) {
+    CLAVA_CHECK_ARG(n && n->n_layers > 0 && n->n_layers <= 64 && n->dims && n->w && n->b && n->act && n->shift_w && n->shift_out,
+                    "%s: incomplete clava_split_net", who);
+    CLAVA_CHECK_ARG(!need_grad || (n->wt && n->shift_grad), "%s: the input gradient needs wt and shift_grad", who);
+    for (int l = 0; l < n->n_layers; ++l) {
+        CLAVA_CHECK_ARG(n->dims[l] > 0 && n->dims[l + 1] > 0 && n->w[l] && (!need_grad || n->wt[l]), "%s: layer %d is empty", who, l);
+        CLAVA_CHECK_ARG(n->act[l] == CLAVA_ACT_NONE || n->act[l] == CLAVA_ACT_RELU || n->act[l] == CLAVA_ACT_LEAKY,
+                        "%s: layer %d: activation %d not supported in a stack", who, l, n->act[l]);
+    }
+    return CLAVA_OK;
+}
+
+// forward of a split stack: outs[l] (split rows, shift_out[l]) for l < n-1, last layer to float32 `last` (ld_last)
+int split_net_forward(const clava_split_net* net, const char* x, int M, const float* rowadd0, char* const* outs, float* last,
+                      int ld_last, int* overflow, hipStream_t st) {
+    const char* in = x;
+    int shift_in = net->shift_in;
+    for (int l = 0; l < net->n_layers; ++l) {
+        const bool is_last = l == net->n_layers - 1;
+        SplitGemmArgs g;
+        g.A = in; g.W = (const char*)net->w[l];
+        g.M = M; g.N = net->dims[l + 1]; g.Kp = (net->dims[l] + 31) & ~31; g.K = net->dims[l];
+        g.pitchA = split_pitch(net->dims[l]); g.pitchW = g.pitchA;
+        g.bias = net->b[l]; g.bias2 = (l == 0) ? rowadd0 : nullptr; g.act = net->act[l];
+        g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
+        g.scale_acc = ldexpf(1.f, -(shift_in + net->shift_w[l]));
+        g.alpha = 1.f;
+        g.scale_out = is_last ? 1.f : ldexpf(1.f, net->shift_out[l]);
+        g.out_split = is_last ? nullptr : outs[l]; g.pitchOut = split_pitch(net->dims[l + 1]);
+        g.out_f32 = is_last ? last : nullptr; g.ldc = ld_last;
+        g.overflow = overflow; g.tiles_m = g.tiles_n = 0;
+        int rc = clava_launch_gemm_f16x3(g, -1, st);
+        if (rc) return rc;
+        in = outs[l];
+        shift_in = net->shift_out[l];
+    }
+    return CLAVA_OK;
+}
+
+// input gradient of a split stack: dlast = split rows (shift_dlast) of d/d(last output); grads[l] (split rows,
+// shift_grad[l]) = d/d(pre-activation of layer l-1) for l >= 1; gx = alpha * d/d(input), float32 [M, dims[0]]
+int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, const char* dlast, char* const* grads, float* gx,
+                         int ld_gx, float alpha, int* overflow, hipStream_t st) {
+    const char* gin = dlast;
+    int shift_g = net->shift_dlast;
+    for (int l = net->n_layers - 1; l >= 0; --l) {
+        SplitGemmArgs g;
+        g.A = gin; g.W = (const char*)net->wt[l];
+        g.M = M; g.N = net->dims[l]; g.Kp = (net->dims[l + 1] + 31) & ~31; g.K = net->dims[l + 1];
+        g.pitchA = split_pitch(net->dims[l + 1]); g.pitchW = g.pitchA;
+        g.bias = nullptr; g.bias2 = nullptr; g.act = CLAVA_ACT_NONE;
+        g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
+        if (l > 0 && net->act[l - 1] != CLAVA_ACT_NONE) {      // derivative of layer l-1's activation, read off its output
+            g.mask = outs[l - 1]; g.pitchMask = split_pitch(net->dims[l]); g.mask_slope = act_slope(net->act[l - 1]);
+        }
+        g.scale_acc = ldexpf(1.f, -(shift_g + net->shift_w[l]));
+        g.alpha = (l == 0) ? alpha : 1.f;
+        g.scale_out = (l == 0) ? 1.f : ldexpf(1.f, net->shift_grad[l]);
+        g.out_split = (l == 0) ? nullptr : grads[l]; g.pitchOut = split_pitch(net->dims[l]);
+        g.out_f32 = (l == 0) ? gx : nullptr; g.ldc = ld_gx;
+        g.overflow = overflow; g.tiles_m = g.tiles_n = 0;
+        int rc = clava_launch_gemm_f16x3(g, -1, st);
+        if (rc) return rc;
+        gin = grads[l];
+        shift_g = (l == 0) ? 0 : net->shift_grad[l];
+    }
+    return CLAVA_OK;
+}
+
+inline long long align256(long long v) { return (v + 255) / 256 * 256; }
+
+struct SplitChainWs {
+    float* x_in;        // [B, D] float32 denoiser input (written by the step kernels)
+    char* x_split;      // the same as split rows
+    char* den[2];       // ping-pong hidden activations
+    float* model_out;   // [B, D]
+    char* cls_out[64];  // classifier activations, kept for the backward pass
+    float* logits;      // [B, C]
+    char* dlogits;      // split rows [B, C]
+    char* cls_grad[2];
+    float* gx;          // [B, n_num]
+    long long total;    // bytes
+};
+
+void carve_split(const clava_chain* c, const clava_split_net* d, const clava_split_net* k, int B, char* base, SplitChainWs& w) {
+    long long off = 0;
+    auto take = [&](long long bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    const int D = d->dims[0];
+    w.x_in = (float*)take(4LL * B * D);
+    w.x_split = take(B * split_pitch(D));
+    const int hw = max_width_dims(d->dims, 1, d->n_layers - 1);
+    w.den[0] = take(B * split_pitch(hw));
+    w.den[1] = take(B * split_pitch(hw));
+    w.model_out = (float*)take(4LL * B * D);
+    w.logits = nullptr; w.dlogits = nullptr; w.gx = nullptr; w.cls_grad[0] = w.cls_grad[1] = nullptr;
+    if (k) {
+        for (int l = 0; l + 1 < k->n_layers; ++l) w.cls_out[l] = take(B * split_pitch(k->dims[l + 1]));
+        const int C = k->dims[k->n_layers];
+        w.logits = (float*)take(4LL * B * C);
+        w.dlogits = take(B * split_pitch(C));
+        const int gw = max_width_dims(k->dims, 1, k->n_layers - 1);
+        w.cls_grad[0] = take(B * split_pitch(gw));
+        w.cls_grad[1] = take(B * split_pitch(gw));
+        w.gx = (float*)take(4LL * B * c->n_num);
+    }
+    w.total = off;
+}
+
+int check_split_chain(const clava_chain* c, const clava_split_net* d, const clava_split_net* k, int B) {
+    CLAVA_CHECK_ARG(c && B > 0, "sample_chain_f16x3: null descriptor or empty batch");
+    CLAVA_CHECK_ARG(c->sched.T > 0 && c->n_steps >= 0 && c->t_start < c->sched.T && c->t_start + 1 >= c->n_steps,
+                    "sample_chain_f16x3: steps t_start=%d n_steps=%d do not fit T=%d", c->t_start, c->n_steps, c->sched.T);
+    int rc = check_split_net(d, false, "sample_chain_f16x3(denoiser)");
+    if (rc) return rc;
+    CLAVA_CHECK_ARG(d->n_layers >= 2, "sample_chain_f16x3: denoiser needs proj + head at least");
+    CLAVA_CHECK_ARG(d->dims[0] == c->n_num + c->sumK && d->dims[d->n_layers] == c->n_num + c->sumK,
+                    "sample_chain_f16x3: denoiser width %d/%d != n_num + sumK = %d", d->dims[0], d->dims[d->n_layers], c->n_num + c->sumK);
+    CLAVA_CHECK_ARG(c->denoiser_emb, "sample_chain_f16x3: denoiser_emb table missing");
+    CLAVA_CHECK_ARG((c->m == 0) == (c->sumK == 0), "sample_chain_f16x3: m / sumK mismatch");
+    CLAVA_CHECK_ARG(c->m == 0 || (c->offsets && c->log_k), "sample_chain_f16x3: offsets / log_k missing");
+    if (k) {
+        rc = check_split_net(k, true, "sample_chain_f16x3(classifier)");
+        if (rc) return rc;
+        CLAVA_CHECK_ARG(k->dims[0] == c->n_num && k->shift_in == d->shift_in,
+                        "sample_chain_f16x3: classifier input (width %d, shift %d) must match the denoiser's numeric input", k->dims[0], k->shift_in);
+        CLAVA_CHECK_ARG(c->m == 0, "sample_chain_f16x3: guidance is Gaussian-only (conditional_sample never carries categories)");
+        CLAVA_CHECK_ARG(c->classifier_emb && c->y, "sample_chain_f16x3: classifier_emb / y missing");
     }
     return CLAVA_OK;
 }
@@ -269,6 +439,98 @@ int clava_sample_chain_f32(const clava_chain* c, int B, double* x, int* idx, flo
             if (rc) return rc;
         }
         // ---- fused categorical step (writes the log-one-hot of the new indices into the next denoiser input)
+        if (c->m > 0) {
+            MultiStepArgs q;
+            q.s = c->sched; q.B = B; q.m = c->m; q.sumK = c->sumK; q.mode = MULTI_MODE_REVERSE;
+            q.logits = w.model_out + c->n_num; q.ld_logits = D;
+            q.idx_in = idx; q.idx_out = idx;
+            q.uniforms = c->uniforms ? c->uniforms + (size_t)s * B * c->sumK : nullptr; q.ld_u = c->sumK;
+            q.x_in = w.x_in + c->n_num; q.ld_xin = D;
+            q.log_prob = nullptr; q.ld_lp = 0;
+            q.offsets = c->offsets; q.log_k = c->log_k;
+            q.t_rows = nullptr; q.t = t;
+            q.seed = c->seed; q.row_offset = c->row_offset; q.step_index = step_index;
+            rc = clava_launch_multinomial_step(q, st);
+            if (rc) return rc;
+        }
+    }
+    return CLAVA_OK;
+}
+
+long long clava_chain_workspace_bytes_f16x3(const clava_chain* c, const clava_split_net* denoiser,
+                                            const clava_split_net* classifier, int B) {
+    if (check_split_chain(c, denoiser, classifier, B)) return -1;
+    SplitChainWs w;
+    carve_split(c, denoiser, classifier, B, nullptr, w);
+    return w.total;
+}
+
+int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denoiser, const clava_split_net* classifier, int B,
+                             double* x, int* idx, void* ws, long long ws_bytes, int* overflow, void* stream) {
+    int rc = check_split_chain(c, denoiser, classifier, B);
+    if (rc) return rc;
+    CLAVA_CHECK_ARG(x || c->n_num == 0, "sample_chain_f16x3: x is null");
+    CLAVA_CHECK_ARG(idx || c->m == 0, "sample_chain_f16x3: idx is null");
+    CLAVA_CHECK_ARG(overflow, "sample_chain_f16x3: the overflow flag is required");
+    SplitChainWs w;
+    carve_split(c, denoiser, classifier, B, (char*)ws, w);
+    CLAVA_CHECK_ARG(ws && ws_bytes >= w.total && ((uintptr_t)ws & 255) == 0,
+                    "sample_chain_f16x3: workspace of %lld bytes (256-byte aligned) needed, %lld given", w.total, ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const clava_split_net* d = denoiser;
+    const clava_split_net* k = classifier;
+    const int D = d->dims[0], nd = d->n_layers;
+    const int emb_w = d->dims[1];
+
+    rc = clava_launch_chain_input(x, idx, c->offsets, w.x_in, B, c->n_num, c->m, c->sumK, st);
+    if (rc) return rc;
+
+    for (int s = 0; s < c->n_steps; ++s) {
+        const int t = c->t_start - s;
+        const unsigned step_index = (unsigned)(c->sched.T - 1 - t);
+        // ---- denoiser input as split rows
+        rc = clava_launch_split_pack(w.x_in, D, B, D, d->shift_in, w.x_split, split_pitch(D), overflow, st);
+        if (rc) return rc;
+        // ---- denoiser forward
+        char* outs[64];
+        for (int l = 0; l < nd - 1; ++l) outs[l] = w.den[l & 1];
+        outs[nd - 1] = nullptr;
+        rc = split_net_forward(d, w.x_split, B, c->denoiser_emb + (size_t)t * emb_w, outs, w.model_out, D, overflow, st);
+        if (rc) return rc;
+        // ---- guidance
+        const float* grad = nullptr;
+        if (k) {
+            const int nk = k->n_layers, C = k->dims[nk];
+            rc = split_net_forward(k, w.x_split, B, c->classifier_emb + (size_t)t * k->dims[1], w.cls_out, w.logits, C, overflow, st);
+            if (rc) return rc;
+            {
+                ProfScope prof(PROF_SELECT_GRAD, 0.0, 8.0 * B * C, st);
+                hipLaunchKernelGGL(logsoftmax_select_grad_split_kernel, dim3((B + 3) / 4), dim3(256), 0, st, w.logits, C, c->y,
+                                   w.dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), B, C);
+                CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
+            }
+            char* grads[64];
+            for (int l = 1; l < nk; ++l) grads[l] = w.cls_grad[l & 1];
+            grads[0] = nullptr;
+            rc = split_net_input_grad(k, B, w.cls_out, w.dlogits, grads, w.gx, c->n_num, c->guidance_scale, overflow, st);
+            if (rc) return rc;
+            grad = w.gx;
+        }
+        if (c->n_num > 0) {
+            GaussStepArgs g;
+            g.s = c->sched; g.B = B; g.n_num = c->n_num;
+            g.eps = w.model_out; g.ld_eps = D;
+            g.x = x;
+            g.grad = grad; g.ld_grad = c->n_num;
+            g.noise = c->noise ? c->noise + (size_t)s * B * c->n_num : nullptr;
+            g.x_in = w.x_in; g.ld_xin = D;
+            g.pred_xstart = nullptr;
+            g.t_rows = nullptr; g.t = t;
+            g.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
+            g.seed = c->seed; g.row_offset = c->row_offset; g.step_index = step_index;
+            rc = clava_launch_gauss_step(g, st);
+            if (rc) return rc;
+        }
         if (c->m > 0) {
             MultiStepArgs q;
             q.s = c->sched; q.B = B; q.m = c->m; q.sumK = c->sumK; q.mode = MULTI_MODE_REVERSE;

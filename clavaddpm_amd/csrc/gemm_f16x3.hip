@@ -1,0 +1,325 @@
+// Split-f16 GEMM on the gfx950 f16 matrix cores: float32-accurate nn.Linear products at (f16 MFMA rate) / 3.
+//
+// Replaces the nn.Linear products of the sampling loop - MLPDiffusion.forward (tab_ddpm/modules.py:451-460),
+// Classifier.forward (pipeline_utils.py:625-630) and the input-gradient chain behind cond_fn
+// (pipeline_utils.py:853-864) - where weights are constant for a whole chain and can be packed once.
+// Number format and accuracy argument: split.h.  The float32-input MFMA kernel (gemm_f32.hip) runs at 1/16 of the
+// f16 MFMA rate; three f16 MFMAs per product leave a 16/3 headroom at the same (f32-level) accuracy.
+//
+// Kernel: out[m][n] = epi( sum_k A[m][k] * W[n][k] ), computed as D = Wtile (rows n) x Atile^T (columns m) so that a
+// lane's four accumulator registers are four consecutive n of one output row m: packed 8-byte stores of each plane.
+//   workgroup 512 threads = 8 waves (WN along n x 8/WN along m), tile BN x BM, one 32-deep k block per stage
+//   (128 B per row: hi plane | lo plane), two LDS stages of (BN + BM) * 128 B, filled by global_load_lds_dwordx4
+//   (16 B per lane, one wave-instruction = 8 rows x 128 B); the next stage's loads are issued before the current
+//   stage's MFMAs and are awaited only at the stage's closing barrier.
+//   LDS image: row-major [row][128 B], 16-B chunk index XOR ((row >> 1) & 7): every ds_read_b128 lane group of a
+//   fragment read (16 rows x one chunk) lands on 16 distinct 16-B bank slots.  The permutation is applied to the
+//   SOURCE address of the LDS-DMA (its LDS side is lane-linear) and to the fragment reads.
+//   v_mfma_f32_16x16x32_f16: lane l supplies row (l & 15), k = 8 * (l >> 4) .. +7 of both operands.
+//   BM is chosen per shape so that the tile count fills the 256 CUs in whole rounds (M = 20000 sampling batches).
+#include "split.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const char* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+}
+
+template <int BN, int BM, int WN>
+__global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
+    constexpr int WM = 8 / WN;
+    constexpr int TN = BN / (16 * WN), TM = BM / (16 * WM);   // 16x16 MFMA tiles per wave
+    constexpr int G = (BN + BM) / 8;                          // 8-row staging groups per stage (one LDS-DMA each)
+    constexpr int Q = (G + 7) / 8;                            // groups per wave (the last one may be absent)
+    constexpr int STAGE = (BN + BM) * 128;
+    static_assert(TN * 16 * WN == BN && TM * 16 * WM == BM && (BN % 16) == 0 && (BM % 16) == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+
+    // XCD-aware tile order (blocks with equal blockIdx % 8 share an XCD and take a contiguous run of tiles: the
+    // column tiles of one activation row panel); bijective for any tile count
+    const int nt = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nt >> 3, rem = nt & 7;
+    const int tile = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (bid >> 3);
+    const int m0 = (tile / g.tiles_n) * BM;
+    const int n0 = (tile % g.tiles_n) * BN;
+    const int nkb = g.Kp >> 5;
+
+    // ---- staging sources: lane i of a group fills LDS row 8*group + (i >> 3), chunk slot (i & 7)
+    const char* src[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int r = (wave + 8 * q) * 8 + (lane >> 3);
+        const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
+        if (r < BN) {
+            const int gr = min(n0 + r, g.N - 1);
+            src[q] = g.W + (long long)gr * g.pitchW + sw;
+        } else {
+            const int gr = min(m0 + (r - BN), g.M - 1);
+            src[q] = g.A + (long long)gr * g.pitchA + sw;
+        }
+    }
+    char* const st = smem + wave * 1024;
+
+    // ---- fragment read offsets (same for every 16-row tile: the swizzle only uses row bits 1..3)
+    const int lrow = lane & 15, kq = lane >> 4, sw = (lrow >> 1) & 7;
+    const int off_hi = lrow * 128 + ((kq ^ sw) << 4);
+    const int off_lo = lrow * 128 + (((4 + kq) ^ sw) << 4);
+    const char* const frW = smem + wn * (BN / WN) * 128;
+    const char* const frA = smem + BN * 128 + wm * (BM / WM) * 128;
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (wave + 8 * q < G) glds16(src[q], st + q * 8192);
+    __syncthreads();
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = (kb & 1) * STAGE, nxt = STAGE - cur;
+        if (kb + 1 < nkb) {
+            const int ko = (kb + 1) * 128;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (wave + 8 * q < G) glds16(src[q] + ko, st + nxt + q * 8192);
+        }
+        h8 ah[TM], al[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            ah[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_hi);
+            al[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const h8 wh = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_hi);
+            const h8 wl = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_lo);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // waits for this wave's LDS-DMA (vmcnt(0)) and for every wave's reads of `cur`
+    }
+
+    // ---- epilogue: lane holds n = nb + 4*(lane >> 4) + r (r = 0..3) of row m = mb + (lane & 15) per 16x16 tile
+    const int Np = (g.N + 31) & ~31;
+    const int n_lane = n0 + wn * (BN / WN) + 4 * kq;
+    const int m_lane = m0 + wm * (BM / WM) + lrow;
+    bool ovf = false;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int nq = n_lane + i * 16;
+        if (nq >= Np) continue;
+        f32x4 bs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nq + r;
+            float b = 0.f;
+            if (n < g.N) {
+                if (g.bias) b += g.bias[n];
+                if (g.bias2) b += g.bias2[n];
+            }
+            bs[r] = b;
+        }
+        const long long col_off = (long long)(nq >> 5) * 128 + ((nq & 31) << 1);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m_lane + j * 16;
+            if (m >= g.M) continue;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] * g.scale_acc + bs[r];
+                if (g.act == CLAVA_ACT_RELU) x = x > 0.f ? x : 0.f;
+                else if (g.act == CLAVA_ACT_LEAKY) x = x > 0.f ? x : 0.01f * x;
+                v[r] = x;
+            }
+            if (g.mask) {
+                const char* mp = g.mask + (long long)m * g.pitchMask + col_off;
+                const h4 mh = *reinterpret_cast<const h4*>(mp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= ((float)mh[r] > 0.f) ? 1.f : g.mask_slope;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (nq + r < g.N) ? v[r] * g.alpha : 0.f;
+            if (g.out_split) {
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = v[r] * g.scale_out;
+                    ovf |= !(fabsf(s) <= 65504.f);
+                    hi[r] = (_Float16)s;
+                    lo[r] = (_Float16)(s - (float)hi[r]);
+                }
+                char* op = g.out_split + (long long)m * g.pitchOut + col_off;
+                *reinterpret_cast<h4*>(op) = hi;
+                *reinterpret_cast<h4*>(op + 64) = lo;
+            }
+            if (g.out_f32) {
+                float* cp = g.out_f32 + (long long)m * g.ldc + nq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nq + r < g.N) cp[r] = v[r];
+            }
+        }
+    }
+    if (ovf && g.overflow) *g.overflow = 1;
+}
+
+// float32 [rows][cols] (ld) -> split rows; one thread per 4 consecutive columns
+__global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict__ src, long long ld, long long rows, int cols,
+                                                         int groups, float scale, char* __restrict__ dst, long long pitch,
+                                                         int* overflow) {
+    const long long total = rows * groups;
+    bool ovf = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / groups;
+        const int c0 = (int)(i - row * groups) << 2;
+        h4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s = (c0 + r < cols) ? src[row * ld + c0 + r] * scale : 0.f;
+            ovf |= !(fabsf(s) <= 65504.f);
+            hi[r] = (_Float16)s;
+            lo[r] = (_Float16)(s - (float)hi[r]);
+        }
+        char* op = dst + row * pitch + (long long)(c0 >> 5) * 128 + ((c0 & 31) << 1);
+        *reinterpret_cast<h4*>(op) = hi;
+        *reinterpret_cast<h4*>(op + 64) = lo;
+    }
+    if (ovf && overflow) *overflow = 1;
+}
+
+__global__ void __launch_bounds__(256) split_unpack_kernel(const char* __restrict__ src, long long pitch, long long rows, int cols,
+                                                           float inv_scale, float* __restrict__ dst, long long ld) {
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / cols;
+        const int c = (int)(i - row * cols);
+        const _Float16* p = reinterpret_cast<const _Float16*>(src + row * pitch + (long long)(c >> 5) * 128) + (c & 31);
+        dst[row * ld + c] = ((float)p[0] + (float)p[32]) * inv_scale;
+    }
+}
+
+inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---- tile configurations ---------------------------------------------------------------------------------------------
+struct TileCfg {
+    int bn, bm;
+    void (*kernel)(SplitGemmArgs);
+};
+#define CLAVA_CFG(BN, BM, WN) {BN, BM, gemm_f16x3_kernel<BN, BM, WN>}
+const TileCfg kCfgs[] = {
+    CLAVA_CFG(256, 320, 2),   // 0: 144 KB LDS, 40 MFMA tiles per wave
+    CLAVA_CFG(256, 256, 2),   // 1
+    CLAVA_CFG(256, 160, 4),   // 2
+    CLAVA_CFG(256, 80, 8),    // 3
+    CLAVA_CFG(128, 320, 2),   // 4
+    CLAVA_CFG(128, 160, 4),   // 5
+    CLAVA_CFG(128, 80, 8),    // 6
+    CLAVA_CFG(64, 128, 4),    // 7: narrow outputs (heads, logits, the input gradient)
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+bool g_attr_set[kNumCfgs] = {};
+
+// cost model (arbitrary units, calibrated on MI355X with tools/bench_f16x3.py): rounds of 256 workgroups x per-k-block
+// time of one tile, the larger of its MFMA time and its LDS-fill time
+int pick_cfg(int M, int N) {
+    int best = kNumCfgs - 1;
+    double best_cost = 1e300;
+    for (int c = 0; c < kNumCfgs; ++c) {
+        const int bn = kCfgs[c].bn, bm = kCfgs[c].bm;
+        if (bn > 64 && N <= bn / 2) continue;
+        const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        const double rounds = (double)((tiles + 255) / 256);
+        const double mfma = (double)bn * bm * 3.0 / 64.0;          // cycles per k block on 4 SIMDs
+        const double fill = (bn + bm) * 128.0 / 48.0;              // cycles per k block at ~48 B/clk/CU from L2
+        const double cost = rounds * ((mfma > fill ? mfma : fill) + 300.0);
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+}  // namespace
+
+int clava_gemm_f16x3_config_count() { return kNumCfgs; }
+
+int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
+    CLAVA_CHECK_ARG(g.A && g.W && (g.out_split || g.out_f32), "gemm_f16x3: null operand");
+    CLAVA_CHECK_ARG(g.M > 0 && g.N > 0 && g.Kp > 0 && g.Kp % 32 == 0, "gemm_f16x3: bad shape M=%d N=%d Kp=%d (Kp must be a multiple of 32)",
+                    g.M, g.N, g.Kp);
+    CLAVA_CHECK_ARG(g.pitchA >= 4LL * g.Kp && g.pitchW >= 4LL * g.Kp && g.pitchA % 16 == 0 && g.pitchW % 16 == 0 &&
+                        aligned(g.A, 16) && aligned(g.W, 16),
+                    "gemm_f16x3: operand rows must be 16-byte aligned and at least 4*Kp bytes apart");
+    const int Np = (g.N + 31) & ~31;
+    CLAVA_CHECK_ARG(!g.out_split || (g.pitchOut >= 4LL * Np && g.pitchOut % 8 == 0 && aligned(g.out_split, 8)),
+                    "gemm_f16x3: output rows must be 8-byte aligned and at least 4*round_up(N,32) bytes apart");
+    CLAVA_CHECK_ARG(!g.mask || (g.pitchMask >= 4LL * Np && g.pitchMask % 8 == 0 && aligned(g.mask, 8)), "gemm_f16x3: bad mask pitch");
+    CLAVA_CHECK_ARG(!g.out_f32 || g.ldc >= g.N, "gemm_f16x3: ldc too small");
+    CLAVA_CHECK_ARG(g.act == CLAVA_ACT_NONE || g.act == CLAVA_ACT_RELU || g.act == CLAVA_ACT_LEAKY, "gemm_f16x3: activation %d", g.act);
+    CLAVA_CHECK_ARG(cfg < kNumCfgs, "gemm_f16x3: tile configuration %d does not exist", cfg);
+    if (cfg < 0) cfg = pick_cfg(g.M, g.N);
+    const TileCfg& tc = kCfgs[cfg];
+    const int lds = 2 * (tc.bn + tc.bm) * 128;
+    if (!g_attr_set[cfg]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tc.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            clava_set_error("gemm_f16x3: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+            return CLAVA_ERR_LAUNCH;
+        }
+        g_attr_set[cfg] = true;
+    }
+    g.tiles_m = (g.M + tc.bm - 1) / tc.bm;
+    g.tiles_n = (g.N + tc.bn - 1) / tc.bn;
+    const double flops = 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp);
+    const double bytes = 4.0 * ((double)g.M * g.Kp + (double)g.N * g.Kp + (double)g.M * g.N);
+    ProfScope prof(PROF_GEMM_F16X3, flops, bytes, stream);
+    hipLaunchKernelGGL(tc.kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+    CLAVA_CHECK_LAUNCH("clava_gemm_f16x3");
+    return CLAVA_OK;
+}
+
+int clava_launch_split_pack(const float* src, long long ld, long long rows, int cols, int shift, char* dst,
+                            long long pitch, int* overflow, hipStream_t stream) {
+    CLAVA_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld >= cols, "split_pack: bad arguments");
+    const int Kp = (cols + 31) & ~31;
+    CLAVA_CHECK_ARG(pitch >= 4LL * Kp && pitch % 8 == 0 && aligned(dst, 8), "split_pack: pitch %lld too small or misaligned", pitch);
+    CLAVA_CHECK_ARG(shift >= -24 && shift <= 24, "split_pack: shift %d out of range", shift);
+    const int groups = Kp / 4;
+    const long long total = rows * groups;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    ProfScope prof(PROF_MISC, 0.0, 8.0 * rows * Kp, stream);
+    hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, groups, ldexpf(1.f, shift), dst,
+                       pitch, overflow);
+    CLAVA_CHECK_LAUNCH("clava_split_pack");
+    return CLAVA_OK;
+}
+
+int clava_launch_split_unpack(const char* src, long long pitch, long long rows, int cols, int shift, float* dst,
+                              long long ld, hipStream_t stream) {
+    CLAVA_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld >= cols, "split_unpack: bad arguments");
+    const int Kp = (cols + 31) & ~31;
+    CLAVA_CHECK_ARG(pitch >= 4LL * Kp, "split_unpack: pitch too small");
+    const long long total = rows * cols;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(split_unpack_kernel, dim3(blocks), dim3(256), 0, stream, src, pitch, rows, cols, ldexpf(1.f, -shift), dst, ld);
+    CLAVA_CHECK_LAUNCH("clava_split_unpack");
+    return CLAVA_OK;
+}

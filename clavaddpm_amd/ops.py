@@ -90,3 +90,71 @@ def linear_wgrad(dy, x, splits=1, out=None, slab_stride=None):
                                      _lib.c_long(slab_stride), c_int(M), c_int(N), c_int(K), c_int(splits), stream_ptr()),
           "clava_gemm_wgrad_f32")
     return out
+
+
+# ---- split-f16 family (csrc/split.h): float32 values as two float16 planes, products on the f16 matrix cores ----------
+class SplitTensor:
+    """A [rows, cols] matrix stored as split rows (see include/clava_hip.h): `buf` is a uint8 device tensor of
+    rows * pitch bytes, `shift` the power-of-two scale of the planes."""
+    __slots__ = ("buf", "rows", "cols", "shift", "pitch")
+
+    def __init__(self, buf, rows, cols, shift, pitch):
+        self.buf, self.rows, self.cols, self.shift, self.pitch = buf, rows, cols, shift, pitch
+
+
+def split_pitch(cols):
+    return 4 * ((cols + 31) // 32 * 32)
+
+
+def split_empty(rows, cols, shift, device):
+    pitch = split_pitch(cols)
+    return SplitTensor(torch.zeros(max(rows * pitch, 1), device=device, dtype=torch.uint8), rows, cols, shift, pitch)
+
+
+def overflow_flag(device):
+    return torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def split_pack(x, shift=0, overflow=None):
+    """float32 [rows, cols] -> SplitTensor (clava_split_pack_f32)."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    rows, cols = x.shape
+    out = split_empty(rows, cols, shift, x.device)
+    if rows:
+        check(lib().clava_split_pack_f32(ptr(x), _lib.c_long(x.stride(0)), _lib.c_long(rows), c_int(cols), c_int(shift),
+                                         ptr(out.buf), _lib.c_long(out.pitch), ptr(overflow), stream_ptr()), "clava_split_pack_f32")
+    return out
+
+
+def split_unpack(s):
+    out = torch.empty((s.rows, s.cols), device=s.buf.device, dtype=torch.float32)
+    if s.rows:
+        check(lib().clava_split_unpack_f32(ptr(s.buf), _lib.c_long(s.pitch), _lib.c_long(s.rows), c_int(s.cols), c_int(s.shift),
+                                           ptr(out), _lib.c_long(out.stride(0)), stream_ptr()), "clava_split_unpack_f32")
+    return out
+
+
+def linear_f16x3(x, w, bias=None, act=None, rowadd=None, act_out=None, slope=0.0, alpha=1.0, out_shift=None, out_f32=False,
+                 overflow=None, tile_config=-1, out=None):
+    """alpha * act'(act_out) * act(x @ w.T + bias + rowadd) with x, w SplitTensors (clava_gemm_f16x3).
+    Returns a SplitTensor with shift `out_shift`, or a float32 tensor when out_f32."""
+    M, K = x.rows, x.cols
+    N = w.rows
+    if w.cols != K:
+        raise _lib.ClavaHipError(f"linear_f16x3: x is [{M},{K}] but w is [{w.rows},{w.cols}]")
+    y_split = y_f32 = None
+    if out_f32:
+        y_f32 = out if out is not None else torch.empty((M, N), device=x.buf.device, dtype=torch.float32)
+    else:
+        y_split = out if out is not None else split_empty(M, N, 0 if out_shift is None else out_shift, x.buf.device)
+    check(lib().clava_gemm_f16x3(ptr(x.buf), _lib.c_long(x.pitch), c_int(x.shift), ptr(w.buf), _lib.c_long(w.pitch), c_int(w.shift),
+                                 ptr(_f32c(bias, "bias")), ptr(_f32c(rowadd, "rowadd")), c_int(_ACT[act]),
+                                 ptr(act_out.buf) if act_out is not None else None,
+                                 _lib.c_long(act_out.pitch if act_out is not None else 0), c_float(slope), c_float(alpha),
+                                 ptr(y_split.buf) if y_split is not None else None,
+                                 _lib.c_long(y_split.pitch if y_split is not None else 0),
+                                 c_int(y_split.shift if y_split is not None else 0), ptr(y_f32),
+                                 c_int(y_f32.stride(0) if y_f32 is not None else 0), c_int(M), c_int(N), c_int(K), ptr(overflow),
+                                 c_int(tile_config), stream_ptr()), "clava_gemm_f16x3")
+    return y_f32 if out_f32 else y_split

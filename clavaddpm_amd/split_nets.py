@@ -1,0 +1,188 @@
+"""Host-side preparation of Linear stacks for the split-f16 matrix-core path (csrc/split.h, clava_gemm_f16x3).
+
+A stack (MLPDiffusion's proj+mlp, `tab_ddpm/modules.py:425-460`, or the eval-mode Classifier,
+`pipeline_utils.py:584-630`) is prepared once per set of weights:
+  * eval-mode BatchNorm below a layer is folded into that layer's weight and bias (W' = W diag(s), b' = b + W c);
+  * weights are packed as split rows (hi/lo float16 planes), plus their transposes for the input-gradient chain;
+  * the power-of-two scale of every activation / gradient plane is calibrated with a float32 pass of the same
+    network (the float32 MFMA kernels) on a fixed synthetic batch, so that magnitudes sit near 2^6: a factor 1000 below
+    the float16 limit.
+The calibration batch depends only on the weights, never on the rows being sampled: a table sampled on 1 or 8 GPUs
+is bit-identical.  If any intermediate still leaves the float16 range the kernels raise an overflow flag and the
+caller reruns the chain on the float32 kernels (`GaussianMultinomialDiffusion._run_chain`).
+
+`set_gemm_mode("f32")` (or CLAVA_GEMM=f32) selects the float32-input MFMA kernels for the sampling loop instead.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+from . import _lib, _native, ops
+from ._lib import ACT_LEAKY, ACT_NONE
+
+_MODES = ("f16x3", "f32")
+_mode = os.environ.get("CLAVA_GEMM", "f16x3")
+if _mode not in _MODES:
+    raise _lib.ClavaHipError(f"CLAVA_GEMM={_mode!r}: expected one of {_MODES}")
+
+# Calibrated activation / gradient magnitudes are scaled into (2^5, 2^6]: a factor 1000 below the float16 limit.  The low
+# plane of the smaller elements then sits in the float16 subnormals, which costs nothing measurable: their absolute
+# error stays 2^-31 of the largest element (tools/dbg_f16x3_range.py: the product's rms error moves from 3.6e-7 to
+# 3.7e-7 between a 2^14 and a 2^6 target on heavy-tailed ReLU data; the float32 MFMA kernel is at the same level).
+TARGET_LOG2 = 6
+IN_TARGET_LOG2 = 5        # the chain state may grow more than hidden activations do
+DLAST_LOG2 = 10           # |onehot - softmax| <= 1 always
+W_TARGET_LOG2 = 12        # weights into (2^11, 2^12]
+CAL_ROWS = 1024
+fallback_count = 0        # chains that left the float16 range and were rerun on the float32 kernels (this process)
+
+
+def set_gemm_mode(mode):
+    """'f16x3' (default): split-f16 layers on the f16 matrix cores; 'f32': the float32-input MFMA kernels."""
+    global _mode
+    if mode not in _MODES:
+        raise ValueError(f"gemm mode must be one of {_MODES}")
+    _mode = mode
+
+
+def get_gemm_mode():
+    return _mode
+
+
+class CSplitNet(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int),
+                ("dims", _native.c_int_p),
+                ("w", ctypes.POINTER(ctypes.c_void_p)),
+                ("wt", ctypes.POINTER(ctypes.c_void_p)),
+                ("b", ctypes.POINTER(ctypes.c_void_p)),
+                ("act", _native.c_int_p),
+                ("shift_w", _native.c_int_p),
+                ("shift_in", ctypes.c_int),
+                ("shift_out", _native.c_int_p),
+                ("shift_grad", _native.c_int_p),
+                ("shift_dlast", ctypes.c_int)]
+
+
+def shift_for(maxabs, target=TARGET_LOG2):
+    """Power-of-two exponent s with maxabs * 2^s in (2^(target-1), 2^target]."""
+    if not (maxabs > 0.0) or not math.isfinite(maxabs):
+        return 0
+    return int(min(24, max(-24, target - math.ceil(math.log2(maxabs)))))
+
+
+def fold_batchnorm(ws, bs, sc, sh):
+    """Fold the eval BatchNorm applied to layer l-1's activated output into layer l: returns float32 (ws', bs')."""
+    fw, fb = [], []
+    for l, (w, b) in enumerate(zip(ws, bs)):
+        w, b = w.detach().float().contiguous(), b.detach().float().contiguous()
+        if l > 0 and sc is not None and sc[l - 1] is not None:
+            b = ops.linear(sh[l - 1].reshape(1, -1).contiguous(), w, b)[0].contiguous()
+            w = (w * sc[l - 1].reshape(1, -1)).contiguous()
+        fw.append(w)
+        fb.append(b)
+    return fw, fb
+
+
+def calibration_input(n_num, offsets, device):
+    """Fixed synthetic denoiser input [CAL_ROWS, n_num + sumK]: N(0,1) numeric columns (the quantile-normalised scale of
+    the chain state, lib/data.py:217-223) and the log-one-hot of a cycling category per feature."""
+    g = torch.Generator().manual_seed(0)
+    cols = [torch.randn(CAL_ROWS, n_num, generator=g)]
+    if offsets is not None and len(offsets) > 1:
+        log_tiny = math.log(1e-30)
+        r = torch.arange(CAL_ROWS)
+        for f in range(len(offsets) - 1):
+            k = int(offsets[f + 1] - offsets[f])
+            blk = torch.full((CAL_ROWS, k), log_tiny)
+            blk[r, r % k] = 0.0
+            cols.append(blk)
+    x = torch.cat(cols, dim=1).float()
+    return x.to(device).contiguous(), float(x.abs().max())
+
+
+class SplitNet:
+    """Packed weights, folded biases and calibrated shifts of one stack; `.c` is the clava_split_net to pass by reference."""
+
+    def __init__(self, ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False):
+        from .tab_ddpm.modules import run_stack
+        dev = ws[0].device
+        n = len(ws)
+        fw, fb = fold_batchnorm(ws, bs, sc, sh)
+        wmax = torch.stack([w.abs().max() for w in fw])
+        # ---- float32 calibration pass at the two ends and the middle of the chain
+        T = emb_table.shape[0]
+        omax = torch.zeros(n, device=dev)
+        gmax = torch.zeros(n, device=dev)
+        for t in sorted({T - 1, T // 2, 0}):
+            outs = run_stack(fw, fb, acts, x_cal[:, :fw[0].shape[1]].contiguous(), rowadd0=emb_table[t])
+            omax = torch.maximum(omax, torch.stack([o.abs().max() for o in outs]))
+            if need_grad:
+                from .pipeline_utils import logsoftmax_select_grad
+                g = logsoftmax_select_grad(outs[-1], y_cal)
+                for l in range(n - 1, 0, -1):
+                    has_act = acts[l - 1] != ACT_NONE
+                    g = ops.linear_dgrad(g, fw[l], act_out=outs[l - 1] if has_act else None,
+                                         slope=0.01 if acts[l - 1] == ACT_LEAKY else 0.0)
+                    gmax[l] = torch.maximum(gmax[l], g.abs().max())
+        stats = torch.cat([wmax, omax, gmax]).cpu().tolist()      # the one host synchronisation of the preparation
+        wmax, omax, gmax = stats[:n], stats[n:2 * n], stats[2 * n:]
+        self.shift_w = [shift_for(v, W_TARGET_LOG2) for v in wmax]
+        self.shift_out = [shift_for(v) for v in omax]
+        self.shift_grad = [shift_for(v) for v in gmax]
+        self.shift_in = shift_in
+        self.shift_dlast = DLAST_LOG2
+        self.w = [ops.split_pack(w, s) for w, s in zip(fw, self.shift_w)]
+        self.wt = [ops.split_pack(w.t().contiguous(), s) for w, s in zip(fw, self.shift_w)] if need_grad else None
+        self.b = fb
+        self.acts = list(acts)
+        self.dims = [fw[0].shape[1]] + [w.shape[0] for w in fw]
+
+        c = CSplitNet()
+        self._dims = (ctypes.c_int * (n + 1))(*self.dims)
+        self._w = _native.void_array([s.buf for s in self.w])
+        self._wt = _native.void_array([s.buf for s in self.wt]) if need_grad else None
+        self._b = _native.void_array(self.b)
+        self._act = (ctypes.c_int * n)(*self.acts)
+        self._sw = (ctypes.c_int * n)(*self.shift_w)
+        self._so = (ctypes.c_int * n)(*self.shift_out)
+        self._sg = (ctypes.c_int * n)(*self.shift_grad)
+        c.n_layers = n
+        c.dims = ctypes.cast(self._dims, _native.c_int_p)
+        c.w = ctypes.cast(self._w, ctypes.POINTER(ctypes.c_void_p))
+        if need_grad:
+            c.wt = ctypes.cast(self._wt, ctypes.POINTER(ctypes.c_void_p))
+            c.shift_grad = ctypes.cast(self._sg, _native.c_int_p)
+        c.b = ctypes.cast(self._b, ctypes.POINTER(ctypes.c_void_p))
+        c.act = ctypes.cast(self._act, _native.c_int_p)
+        c.shift_w = ctypes.cast(self._sw, _native.c_int_p)
+        c.shift_in = shift_in
+        c.shift_out = ctypes.cast(self._so, _native.c_int_p)
+        c.shift_dlast = self.shift_dlast
+        self.c = c
+
+
+_cache = {}
+
+
+def _signature(tensors):
+    """Value fingerprint of the weights (the optimizer kernel updates parameters through raw pointers, which torch's
+    version counters do not see)."""
+    parts = [t.detach().double().sum() + (t.detach().double() ** 2).sum() * 3.0 for t in tensors if t is not None]
+    return torch.stack(parts).sum()
+
+
+def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False):
+    """SplitNet for these weights, cached until any weight value changes."""
+    tensors = list(ws) + list(bs) + list(sc or []) + list(sh or [])
+    key = tuple((t.data_ptr(), tuple(t.shape)) for t in list(ws) + list(bs)) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1])
+    sig = _signature(tensors + [emb_table])
+    hit = _cache.get(key)
+    if hit is not None and bool(hit[1] == sig):
+        return hit[0]
+    net = SplitNet(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal, need_grad)
+    if key not in _cache and len(_cache) >= 8:
+        _cache.pop(next(iter(_cache)))
+    _cache[key] = (net, sig, list(ws) + list(bs))
+    return net

@@ -21,7 +21,7 @@ import ctypes
 import numpy as np
 import torch
 
-from .. import _lib, _native
+from .. import _lib, _native, split_nets
 from .._lib import c_int, c_u64, check, lib, ptr, require_cuda, stream_ptr
 from . import schedule as _schedule
 from .modules import run_stack, time_embed_forward, timestep_embedding
@@ -218,6 +218,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         c.denoiser = ctypes.pointer(den)
         c.denoiser_emb = den_emb.data_ptr()
         keep = [keep_d, den_emb]
+        cls_emb = None
         if guidance is not None:
             clf = guidance.classifier
             if clf.training:
@@ -241,6 +242,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                 u = noise["u"][:n_steps].to(dev).float().contiguous()
                 c.uniforms = u.data_ptr()
                 keep.append(u)
+        if split_nets.get_gemm_mode() == "f16x3":
+            done = self._run_chain_f16x3(c, x, idx, ws, bs, acts, den_emb, guidance, cls_emb, keep)
+            if done:
+                return keep
         need = lib().clava_chain_workspace_floats
         need.restype = ctypes.c_longlong
         n_ws = need(ctypes.byref(c), c_int(B))
@@ -249,7 +254,52 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         wsbuf = torch.empty(int(n_ws), device=dev, dtype=torch.float32)
         check(lib().clava_sample_chain_f32(ctypes.byref(c), c_int(B), ptr(x), ptr(idx) if idx is not None else None, ptr(wsbuf),
                                            ctypes.c_longlong(int(n_ws)), stream_ptr()), "clava_sample_chain_f32")
+        keep.append(wsbuf)
         return keep  # caller keeps these alive until it synchronises
+
+    def _run_chain_f16x3(self, c, x, idx, ws, bs, acts, den_emb, guidance, cls_emb, keep):
+        """The same chain with every Linear on the f16 matrix cores (split-f16, float32-level accuracy: csrc/split.h).
+        Returns False - with x / idx restored - when an intermediate left the float16 range, so that the caller reruns
+        the chain on the float32 kernels."""
+        dev = self._device()
+        B = x.shape[0]
+        offs = self._offsets_i32.cpu().tolist() if self.has_cat else None
+        x_cal, cal_max = split_nets.calibration_input(self.num_numerical_features, offs, dev)
+        shift_in = split_nets.shift_for(cal_max, split_nets.IN_TARGET_LOG2)
+        den = split_nets.prepare(ws, bs, acts, None, None, den_emb, x_cal, shift_in)
+        cls = None
+        if guidance is not None:
+            clf = guidance.classifier
+            cw, cb, cacts, sc, sh = clf.stack()
+            n_cls = cw[-1].shape[0]
+            y_cal = (torch.arange(split_nets.CAL_ROWS, device=dev) % n_cls).to(torch.int32)
+            cls = split_nets.prepare([w.detach() for w in cw], [b.detach() for b in cb], cacts, sc, sh, cls_emb, x_cal, shift_in,
+                                     y_cal=y_cal, need_grad=True)
+        x0 = x.clone()
+        idx0 = idx.clone() if idx is not None else None
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        L = lib()
+        L.clava_chain_workspace_bytes_f16x3.restype = ctypes.c_longlong
+        cp = ctypes.byref(cls.c) if cls is not None else None
+        n_ws = L.clava_chain_workspace_bytes_f16x3(ctypes.byref(c), ctypes.byref(den.c), cp, c_int(B))
+        if n_ws < 0:
+            check(-1, "clava_chain_workspace_bytes_f16x3")
+        wsbuf = torch.zeros(int(n_ws) + 256, device=dev, dtype=torch.uint8)
+        base = wsbuf.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        check(L.clava_sample_chain_f16x3(ctypes.byref(c), ctypes.byref(den.c), cp, c_int(B), ptr(x),
+                                         ptr(idx) if idx is not None else None, ctypes.c_void_p(aligned),
+                                         ctypes.c_longlong(int(n_ws)), ptr(flag), stream_ptr()), "clava_sample_chain_f16x3")
+        keep += [den, cls, wsbuf, flag]
+        if int(flag.item()) != 0:       # synchronises; rare: a magnitude 64x beyond the calibrated range
+            import warnings
+            split_nets.fallback_count += 1
+            warnings.warn("split-f16 chain left the float16 range; rerunning this batch on the float32 MFMA kernels")
+            x.copy_(x0)
+            if idx is not None:
+                idx.copy_(idx0)
+            return False
+        return True
 
     def _initial_state(self, b, noise, seed, row_offset):
         require_cuda(self.log_alpha)          # no CPU path: fail before anything is computed

@@ -69,6 +69,32 @@ int clava_gemm_dgrad_f32(const float* dy, int lddy, const float* w, int ldw, con
 int clava_gemm_wgrad_f32(const float* dy, int lddy, const float* x, int ldx, float* dw_slabs, int lddw,
                          long long slab_stride, int M, int N_out, int K_in, int splits, void* stream);
 
+/* ---- dense layers on the f16 matrix cores at float32 accuracy ("split-f16", clavaddpm_amd/csrc/split.h) ---------
+ * Same nn.Linear products as above (tab_ddpm/modules.py:153-158, 459; pipeline_utils.py:597-630; the input gradient
+ * behind cond_fn, pipeline_utils.py:864), for the sampling loop where weights are constant over a chain.  A float32
+ * value v is stored as two float16 planes hi = f16(v*2^shift), lo = f16(v*2^shift - hi) (22 significand bits); a
+ * product is three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) into a float32 accumulator.
+ * "Split rows": row-major, columns padded to a multiple of 32 (pad = 0), each 32-column block = 32 hi halves then
+ * 32 lo halves (128 bytes); `pitch` = bytes per row, >= 4*round_up(cols,32), a multiple of 16.
+ *
+ * clava_split_pack_f32 / clava_split_unpack_f32 convert float32 [rows, cols] (leading dimension ld) to / from split
+ * rows.  *overflow (device int, may be NULL) is set to 1 if a scaled magnitude exceeds the float16 range. */
+int clava_split_pack_f32(const float* src, long long ld, long long rows, int cols, int shift, void* dst, long long pitch,
+                         int* overflow, void* stream);
+int clava_split_unpack_f32(const void* src, long long pitch, long long rows, int cols, int shift, float* dst, long long ld,
+                           void* stream);
+
+/* y[M,N] = alpha * act'(act_out)[M,N] * act( x[M,K] . w[N,K]^T + bias[N] + rowadd[N] )
+ * x, w: split rows with shifts shift_x, shift_w; y_split (shift_y) and/or y_f32 (ldy) receive the result; act_out
+ * (split rows [M,N], any shift; or NULL) supplies the activation-derivative factor (1 where > 0 else `slope`) of the
+ * input-gradient chain; rowadd is the broadcast time-embedding row.  tile_config < 0 picks the tile for the shape
+ * (0 .. clava_gemm_f16x3_config_count_()-1 force one: tools/bench_f16x3.py). */
+int clava_gemm_f16x3(const void* x, long long pitch_x, int shift_x, const void* w, long long pitch_w, int shift_w,
+                     const float* bias, const float* rowadd, int act, const void* act_out, long long pitch_act, float slope,
+                     float alpha, void* y_split, long long pitch_y, int shift_y, float* y_f32, int ldy, int M, int N, int K,
+                     int* overflow, int tile_config, void* stream);
+int clava_gemm_f16x3_config_count_(void);
+
 /* ---- schedule tables ---------------------------------------------------------------------------------------
  * Device-resident tables of length T, built by the host exactly as GaussianMultinomialDiffusion.__init__ builds
  * them (tab_ddpm/gaussian_multinomial_diffsuion.py:105-156); model_variance is the "fixed-large" variance the
@@ -195,6 +221,38 @@ long long clava_chain_workspace_floats(const clava_chain* c, int B);
 /* x [B,n_num] float64 (in: x at t_start, out: x after n_steps steps), idx [B,m] int32 likewise; ws = device workspace. */
 int clava_sample_chain_f32(const clava_chain* c, int B, double* x, int* idx, float* ws, long long ws_floats,
                            void* stream);
+
+/* ---- whole reverse chain on the f16 matrix cores (split-f16 layers, float32-level accuracy) --------------------
+ * A Linear stack prepared for clava_gemm_f16x3: w[l] = layer l's weight as split rows [dims[l+1], dims[l]] with
+ * shift shift_w[l]; an eval-mode BatchNorm below a layer (pipeline_utils.py:609, 616) is folded into that layer's
+ * weight and bias by the host (W' = W diag(scale), b' = b + W shift).  wt[l] = the same matrix transposed (split rows
+ * [dims[l], dims[l+1]], same shift) for the input-gradient chain; wt and shift_grad may be NULL for a stack that is
+ * only run forward.  shift_in / shift_out[l] / shift_grad[l] / shift_dlast are the power-of-two scales of the input,
+ * of layer l's activation planes, of the gradient planes d/d(pre-activation of layer l-1) and of the d/d(logits)
+ * planes, chosen by the host from a float32 calibration pass so that magnitudes sit near 2^6.  All arrays are HOST
+ * arrays of device pointers / ints. */
+typedef struct clava_split_net {
+    int n_layers;
+    const int* dims;
+    const void* const* w;
+    const void* const* wt;
+    const float* const* b;
+    const int* act;
+    const int* shift_w;
+    int shift_in;
+    const int* shift_out;
+    const int* shift_grad;
+    int shift_dlast;
+} clava_split_net;
+
+/* Same chain as clava_sample_chain_f32 (same step kernels, same noise keys) with every nn.Linear product on
+ * clava_gemm_f16x3; c->denoiser / c->classifier are ignored (c->classifier_emb, c->y, c->guidance_scale are used when
+ * `classifier` is not NULL).  *overflow (device int, zeroed by the caller) becomes 1 if any intermediate left the
+ * float16 range: the result is then invalid and the caller reruns the chain with clava_sample_chain_f32. */
+long long clava_chain_workspace_bytes_f16x3(const clava_chain* c, const clava_split_net* denoiser,
+                                            const clava_split_net* classifier, int B);
+int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denoiser, const clava_split_net* classifier, int B,
+                             double* x, int* idx, void* ws, long long ws_bytes, int* overflow, void* stream);
 
 /* ---- training step ------------------------------------------------------------------------------------------
  * Gaussian 'mse' loss and its gradient: loss_rows[b] = mean_c (noise - model_out)^2, d_out[b,c] = 2 (model_out -

@@ -1,0 +1,126 @@
+"""GPU parity of the split-f16 ("f16x3") layer kernels, through the C ABI: float32-level accuracy on the f16 matrix
+cores (csrc/split.h).  Bars: the same as the float32 MFMA kernels (2e-6 of the largest output per product against a
+float64 reference; chains within 1e-4 of the reference's golden vectors, categories exact - tests/test_gpu_parity.py
+runs every chain on both kernel families)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import golden, relerr, sub
+
+from clavaddpm_amd import _lib, ops, split_nets
+from clavaddpm_amd.pipeline_utils import Classifier, make_cond_fn
+from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+
+DEV = "cuda"
+
+
+def _gen(seed):
+    return torch.Generator(device=DEV).manual_seed(seed)
+
+
+def test_pack_unpack_round_trip():
+    g = _gen(1)
+    x = torch.randn(301, 77, device=DEV, generator=g) * torch.exp(2 * torch.randn(301, 77, device=DEV, generator=g))
+    flag = ops.overflow_flag(DEV)
+    x = x.clamp(-2000.0, 2000.0)
+    for shift in (-3, 0, 4):
+        s = ops.split_pack(x, shift, flag)
+        assert s.pitch == 4 * 96
+        back = ops.split_unpack(s)
+        assert float((back - x).abs().max() / x.abs().max()) < 2.5e-7       # 22 significand bits of the largest element
+    assert int(flag.item()) == 0
+    ops.split_pack(x * 1e6, 6, flag)
+    assert int(flag.item()) == 1                                            # out of the float16 range: flagged, not silent
+
+
+@pytest.mark.parametrize("M,N,K", [(333, 70, 45), (1000, 300, 96), (513, 1024, 128), (700, 50, 128), (321, 2, 512), (5, 3, 1),
+                                   (20000, 512, 1024)])
+def test_linear_every_tile_configuration(M, N, K):
+    g = _gen(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) * 0.1      # asymmetric operands: a transposed C map cannot pass
+    b = torch.randn(N, device=DEV, generator=g)
+    ref = (x.double() @ w.double().T + b.double()).clamp_min(0)
+    flag = ops.overflow_flag(DEV)
+    xs, wsp = ops.split_pack(x, 3, flag), ops.split_pack(w, 12, flag)
+    n_cfg = _lib.lib().clava_gemm_f16x3_config_count_()
+    for cfg in range(-1, n_cfg if M < 5000 else 0):
+        y = ops.linear_f16x3(xs, wsp, b, act="relu", out_shift=5, overflow=flag, tile_config=cfg)
+        assert relerr(ops.split_unpack(y), ref) < 2e-6, cfg
+        yf = ops.linear_f16x3(xs, wsp, b, act="relu", out_f32=True, overflow=flag, tile_config=cfg)
+        assert relerr(yf, ref) < 2e-6, cfg
+        # pad columns of the split output are zero (they are the next layer's K padding)
+        raw = y.buf.view(M, y.pitch).view(torch.float16).view(M, -1, 64)
+        pad = torch.arange(32, device=DEV)[None, :] + 32 * torch.arange(raw.shape[1], device=DEV)[:, None] >= N
+        assert bool((raw[:, :, :32][:, pad] == 0).all() and (raw[:, :, 32:][:, pad] == 0).all()), cfg
+    assert int(flag.item()) == 0
+
+
+def test_linear_identity_and_gradient_epilogue():
+    n = 96
+    eye = ops.split_pack(torch.eye(n, device=DEV), 0)
+    w = torch.arange(n * n, device=DEV, dtype=torch.float32).reshape(n, n) / 64.0
+    out = ops.linear_f16x3(eye, ops.split_pack(w, 0), out_f32=True)
+    assert torch.equal(out, w.T.contiguous())            # integers / 64 below 2^22: exact in 22 bits
+    # input-gradient epilogue: alpha * act'(act_out) * (dy @ W) with W given transposed
+    g = _gen(9)
+    M, N, K = 200, 130, 64
+    dy = torch.randn(M, N, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.2
+    a = torch.randn(M, K, device=DEV, generator=g)
+    ref = 1.5 * torch.where(a > 0, 1.0, 0.01).double() * (dy.double() @ W.double())
+    got = ops.linear_f16x3(ops.split_pack(dy, 8), ops.split_pack(W.t().contiguous(), 10), act_out=ops.split_pack(a, 2), slope=0.01,
+                           alpha=1.5, out_f32=True)
+    assert relerr(got, ref) < 2e-6
+
+
+def _cond_setup():
+    g = golden("g5_chain_cond.npz")
+    T, n_num, C = int(g["T"]), int(g["n_num"]), int(g["C"])
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": [64, 64], "dropout": 0.0})
+    net.load_state_dict(sub(g, "p:"))
+    clf = Classifier(d_in=n_num, d_out=C, dim_t=128, hidden_sizes=g["hidden"].tolist())
+    clf.load_state_dict(sub(g, "c:"))
+    d = GaussianMultinomialDiffusion(np.array([0]), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    return g, d, clf.to(DEV).eval()
+
+
+def test_overflow_falls_back_to_float32_and_still_matches():
+    """A chain whose state leaves the float16 range (here: the guidance scaled by 1e9) must not return garbage: the flag
+    is raised, the batch is rerun on the float32 kernels, and the result equals the float32 run."""
+    g, d, clf = _cond_setup()
+    ys = g["ys"]
+    split_nets.set_gemm_mode("f32")
+    ref, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1e9), noise=sub(g, "nz:"), n_steps=6)
+    split_nets.set_gemm_mode("f16x3")
+    n0 = split_nets.fallback_count
+    with pytest.warns(UserWarning, match="float16 range"):
+        x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1e9), noise=sub(g, "nz:"), n_steps=6)
+    assert split_nets.fallback_count == n0 + 1
+    assert torch.equal(x, ref)
+
+
+def test_full_size_chain_matches_float32_kernels():
+    """BASELINE configs[1] shapes (20000 rows, [512,1024x4,512] denoiser, 7-layer classifier): 8 guided steps on both
+    kernel families from the same seed agree to float32 rounding."""
+    from weights import classifier_shapes, mlp_shapes, seeded_state
+    dl, cl, n_num, C, T = [512, 1024, 1024, 1024, 1024, 512], [128, 256, 512, 1024, 512, 256, 128], 2, 50, 1000
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(dl), "dropout": 0.0})
+    net.load_state_dict(seeded_state(mlp_shapes(n_num, dl), 3))
+    clf = Classifier(d_in=n_num, d_out=C, dim_t=128, hidden_sizes=cl)
+    clf.load_state_dict(seeded_state(classifier_shapes(n_num, C, cl), 4))
+    d = GaussianMultinomialDiffusion(np.array([0]), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    ys = torch.randint(0, C, (20000, 1), generator=torch.Generator().manual_seed(0))
+    cf = make_cond_fn(clf.to(DEV).eval(), 1.0)
+    out = {}
+    n0 = split_nets.fallback_count
+    for mode in ("f16x3", "f32"):
+        split_nets.set_gemm_mode(mode)
+        out[mode], _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, seed=11, n_steps=8)
+    split_nets.set_gemm_mode("f16x3")
+    assert split_nets.fallback_count == n0
+    assert torch.isfinite(out["f32"]).all()
+    assert relerr(out["f16x3"], out["f32"]) < 1e-5

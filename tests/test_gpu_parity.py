@@ -18,6 +18,19 @@ from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion, t
 DEV = "cuda"
 
 
+@pytest.fixture(params=["f16x3", "f32"], autouse=True)
+def gemm_mode(request):
+    """Every test of this file runs on both layer-kernel families of the sampling loop: split-f16 on the f16 matrix
+    cores (the default) and the float32-input MFMA kernels; the tolerances are the same."""
+    from clavaddpm_amd import split_nets
+    before = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode(request.param)
+    n0 = split_nets.fallback_count
+    yield request.param
+    split_nets.set_gemm_mode(before)
+    assert split_nets.fallback_count == n0, "the split-f16 chain fell back to float32 on a golden fixture"
+
+
 def make_mlp(d_in, d_layers, state):
     net = MLPDiffusion(d_in, 0, "none", {"d_layers": list(d_layers), "dropout": 0.0})
     net.load_state_dict(state)
