@@ -7,7 +7,8 @@
 // f16 MFMA rate; three f16 MFMAs per product leave a 16/3 headroom at the same (f32-level) accuracy.
 //
 // Kernel: out[m][n] = epi( sum_k A[m][k] * W[n][k] ), computed as D = Wtile (rows n) x Atile^T (columns m) so that a
-// lane's four accumulator registers are four consecutive n of one output row m: packed 8-byte stores of each plane.
+// lane's four accumulator registers are four consecutive n of one output row m; W rows are staged permuted so that an
+// even/odd tile pair gives a lane eight consecutive n: packed 16-byte stores of each plane, full 128-byte lines per row.
 //   workgroup 512 threads = 8 waves (WN along n x 8/WN along m), tile BN x BM, one 32-deep k block per stage
 //   (128 B per row: hi plane | lo plane), two LDS stages of (BN + BM) * 128 B, filled by global_load_lds_dwordx4
 //   (16 B per lane, one wave-instruction = 8 rows x 128 B); the next stage's loads are issued before the current
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     constexpr int G = (BN + BM) / 8;                          // 8-row staging groups per stage (one LDS-DMA each)
     constexpr int Q = (G + 7) / 8;                            // groups per wave (the last one may be absent)
     constexpr int STAGE = (BN + BM) * 128;
+    constexpr int SPREAD = TN >= 2 ? TN / 2 : 1;             // MFMA groups over which a stage's LDS-DMA issue is spread
     static_assert(TN * 16 * WN == BN && TM * 16 * WM == BM && (BN % 16) == 0 && (BM % 16) == 0, "tile shape");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -63,7 +65,9 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         const int r = (wave + 8 * q) * 8 + (lane >> 3);
         const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
         if (r < BN) {
-            const int gr = min(n0 + r, g.N - 1);
+            // LDS row 32*p + 16*b + 4*q + rr holds output column 32*p + 8*q + 4*b + rr (epilogue: 8 consecutive columns per lane)
+            const int pr = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
+            const int gr = min(n0 + pr, g.N - 1);
             src[q] = g.W + (long long)gr * g.pitchW + sw;
         } else {
             const int gr = min(m0 + (r - BN), g.M - 1);
@@ -92,12 +96,8 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
 
     for (int kb = 0; kb < nkb; ++kb) {
         const int cur = (kb & 1) * STAGE, nxt = STAGE - cur;
-        if (kb + 1 < nkb) {
-            const int ko = (kb + 1) * 128;
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-                if (wave + 8 * q < G) glds16(src[q] + ko, st + nxt + q * 8192);
-        }
+        const bool more = kb + 1 < nkb;
+        const int ko = (kb + 1) * 128;
         h8 ah[TM], al[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -108,6 +108,14 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         for (int i = 0; i < TN; ++i) {
             const h8 wh = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_hi);
             const h8 wl = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_lo);
+            // the next stage's LDS-DMA is issued behind the fragment reads of the first half of the wave's MFMA groups:
+            // its issue cost (~100 cycles per instruction) hides under MFMAs instead of delaying the first fragment read,
+            // and the second half of the groups gives the data time to land before the closing barrier
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if ((q * SPREAD) / Q == i && wave + 8 * q < G) glds16(src[q] + ko, st + nxt + q * 8192);
+            }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[j], acc[i][j], 0, 0, 0);
@@ -118,18 +126,23 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         __syncthreads();   // waits for this wave's LDS-DMA (vmcnt(0)) and for every wave's reads of `cur`
     }
 
-    // ---- epilogue: lane holds n = nb + 4*(lane >> 4) + r (r = 0..3) of row m = mb + (lane & 15) per 16x16 tile
+    // ---- epilogue.  W rows are staged permuted (see the staging sources): within every 32-column block, MFMA tile
+    // b (0/1) row 4*q + r holds column 8*q + 4*b + r, so a lane's accumulators of an even/odd tile pair are 8
+    // CONSECUTIVE columns of one output row: one 16-byte store per plane, and the four lanes of a row fill the row's
+    // whole 128-byte block (64 B hi | 64 B lo).  Configurations with one tile per wave store 4 columns (8 bytes).
+    constexpr int EW = (TN % 2 == 0) ? 8 : 4;               // columns per lane per store
+    constexpr int EP = (TN % 2 == 0) ? TN / 2 : TN;         // stores per output row per plane
     const int Np = (g.N + 31) & ~31;
-    const int n_lane = n0 + wn * (BN / WN) + 4 * kq;
     const int m_lane = m0 + wm * (BM / WM) + lrow;
     bool ovf = false;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int nq = n_lane + i * 16;
+    for (int ip = 0; ip < EP; ++ip) {
+        const int it = wn * TN + (EW == 8 ? 2 * ip : ip);    // n-subtile index inside the workgroup tile
+        const int nq = n0 + 32 * (it >> 1) + 8 * kq + 4 * (it & 1);
         if (nq >= Np) continue;
-        f32x4 bs;
+        float bs[EW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < EW; ++r) {
             const int n = nq + r;
             float b = 0.f;
             if (n < g.N) {
@@ -143,39 +156,47 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         for (int j = 0; j < TM; ++j) {
             const int m = m_lane + j * 16;
             if (m >= g.M) continue;
-            f32x4 v;
+            float v[EW];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * g.scale_acc + bs[r];
+            for (int r = 0; r < EW; ++r) {
+                const float a = (EW == 8) ? acc[2 * ip + (r >> 2)][j][r & 3] : acc[ip][j][r & 3];
+                float x = a * g.scale_acc + bs[r];
                 if (g.act == CLAVA_ACT_RELU) x = x > 0.f ? x : 0.f;
                 else if (g.act == CLAVA_ACT_LEAKY) x = x > 0.f ? x : 0.01f * x;
                 v[r] = x;
             }
             if (g.mask) {
                 const char* mp = g.mask + (long long)m * g.pitchMask + col_off;
-                const h4 mh = *reinterpret_cast<const h4*>(mp);
+                _Float16 mh[EW];
+                if constexpr (EW == 8) *reinterpret_cast<h8*>(mh) = *reinterpret_cast<const h8*>(mp);
+                else *reinterpret_cast<h4*>(mh) = *reinterpret_cast<const h4*>(mp);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= ((float)mh[r] > 0.f) ? 1.f : g.mask_slope;
+                for (int r = 0; r < EW; ++r) v[r] *= ((float)mh[r] > 0.f) ? 1.f : g.mask_slope;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (nq + r < g.N) ? v[r] * g.alpha : 0.f;
+            for (int r = 0; r < EW; ++r) v[r] = (nq + r < g.N) ? v[r] * g.alpha : 0.f;
             if (g.out_split) {
-                h4 hi, lo;
+                _Float16 hi[EW], lo[EW];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = v[r] * g.scale_out;
-                    ovf |= !(fabsf(s) <= 65504.f);
-                    hi[r] = (_Float16)s;
-                    lo[r] = (_Float16)(s - (float)hi[r]);
+                for (int r = 0; r < EW; ++r) {
+                    const float sc = v[r] * g.scale_out;
+                    ovf |= !(fabsf(sc) <= 65504.f);
+                    hi[r] = (_Float16)sc;
+                    lo[r] = (_Float16)(sc - (float)hi[r]);
                 }
                 char* op = g.out_split + (long long)m * g.pitchOut + col_off;
-                *reinterpret_cast<h4*>(op) = hi;
-                *reinterpret_cast<h4*>(op + 64) = lo;
+                if constexpr (EW == 8) {
+                    *reinterpret_cast<h8*>(op) = *reinterpret_cast<const h8*>(hi);
+                    *reinterpret_cast<h8*>(op + 64) = *reinterpret_cast<const h8*>(lo);
+                } else {
+                    *reinterpret_cast<h4*>(op) = *reinterpret_cast<const h4*>(hi);
+                    *reinterpret_cast<h4*>(op + 64) = *reinterpret_cast<const h4*>(lo);
+                }
             }
             if (g.out_f32) {
                 float* cp = g.out_f32 + (long long)m * g.ldc + nq;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < EW; ++r)
                     if (nq + r < g.N) cp[r] = v[r];
             }
         }
@@ -228,15 +249,16 @@ struct TileCfg {
 #define CLAVA_CFG(BN, BM, WN) {BN, BM, gemm_f16x3_kernel<BN, BM, WN>}
 const TileCfg kCfgs[] = {
     CLAVA_CFG(256, 320, 2),   // 0: 144 KB LDS, 40 MFMA tiles per wave
-    CLAVA_CFG(256, 256, 2),   // 1
+    CLAVA_CFG(128, 96, 4),    // 1: 128-wide layers at M = 20000 (209 tiles)
     CLAVA_CFG(256, 160, 4),   // 2
     CLAVA_CFG(256, 80, 8),    // 3
     CLAVA_CFG(128, 320, 2),   // 4
     CLAVA_CFG(128, 160, 4),   // 5
     CLAVA_CFG(128, 80, 8),    // 6
-    CLAVA_CFG(64, 128, 4),    // 7: narrow outputs (heads, logits, the input gradient)
+    CLAVA_CFG(64, 128, 2),    // 7: narrow outputs (heads, logits, the input gradient)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
 bool g_attr_set[kNumCfgs] = {};
 
 // cost model (arbitrary units, calibrated on MI355X with tools/bench_f16x3.py): rounds of 256 workgroups x per-k-block
@@ -290,7 +312,7 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     g.tiles_n = (g.N + tc.bn - 1) / tc.bn;
     const double flops = 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp);
     const double bytes = 4.0 * ((double)g.M * g.Kp + (double)g.N * g.Kp + (double)g.M * g.N);
-    ProfScope prof(PROF_GEMM_F16X3, flops, bytes, stream);
+    ProfScope prof(PROF_GEMM_F16X3 + cfg, flops, bytes, stream);
     hipLaunchKernelGGL(tc.kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
     CLAVA_CHECK_LAUNCH("clava_gemm_f16x3");
     return CLAVA_OK;
