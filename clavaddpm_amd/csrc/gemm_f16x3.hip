@@ -33,7 +33,7 @@ __device__ __forceinline__ void glds16(const char* src, char* dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
 }
 
-template <int BN, int BM, int WN>
+template <int BN, int BM, int WN, int NS>
 __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     constexpr int WM = 8 / WN;
     constexpr int TN = BN / (16 * WN), TM = BM / (16 * WM);   // 16x16 MFMA tiles per wave
@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     constexpr int Q = (G + 7) / 8;                            // groups per wave (the last one may be absent)
     constexpr int STAGE = (BN + BM) * 128;
     constexpr int SPREAD = TN >= 2 ? TN / 2 : 1;             // MFMA groups over which a stage's LDS-DMA issue is spread
+    static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS stages");
     static_assert(TN * 16 * WN == BN && TM * 16 * WM == BM && (BN % 16) == 0 && (BM % 16) == 0, "tile shape");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -58,12 +59,17 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     const int n0 = (tile % g.tiles_n) * BN;
     const int nkb = g.Kp >> 5;
 
-    // ---- staging sources: lane i of a group fills LDS row 8*group + (i >> 3), chunk slot (i & 7)
+    // ---- staging sources: lane i of a group fills LDS row 8*group + (i >> 3), chunk slot (i & 7).  Every wave issues
+    // exactly Q DMAs per stage (a wave without a last group re-issues its previous one: same source, same destination)
+    // so that the counted vmcnt waits below mean the same thing in every wave.
     const char* src[Q];
+    int dst[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int r = (wave + 8 * q) * 8 + (lane >> 3);
+        const int qq = (wave + 8 * q < G) ? q : q - 1;
+        const int r = (wave + 8 * qq) * 8 + (lane >> 3);
         const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
+        dst[q] = qq * 8192;
         if (r < BN) {
             // LDS row 32*p + 16*b + 4*q + rr holds output column 32*p + 8*q + 4*b + rr (epilogue: 8 consecutive columns per lane)
             const int pr = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
@@ -89,15 +95,21 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- NS-stage pipeline: stages kb+1 .. kb+NS-1 are in flight while stage kb is multiplied.  The waits are counted
+    // (`vmcnt(Q*(NS-2))` = everything but the NS-2 youngest stages has landed) and the barriers raw: __syncthreads()
+    // would drain the whole DMA queue (vmcnt(0)) at every k block.
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
-        if (wave + 8 * q < G) glds16(src[q], st + q * 8192);
-    __syncthreads();
+    for (int s0 = 0; s0 < NS - 1; ++s0) {
+        const int ko = min(s0, nkb - 1) * 128;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) glds16(src[q] + ko, st + s0 * STAGE + dst[q]);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
 
+    int cur = 0, nxt = (NS - 1) * STAGE;                     // byte offsets of the stage read now / filled now
     for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = (kb & 1) * STAGE, nxt = STAGE - cur;
-        const bool more = kb + 1 < nkb;
-        const int ko = (kb + 1) * 128;
+        const bool more = kb + NS - 1 < nkb;
+        const int ko = (kb + NS - 1) * 128;
         h8 ah[TM], al[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -108,13 +120,12 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         for (int i = 0; i < TN; ++i) {
             const h8 wh = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_hi);
             const h8 wl = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_lo);
-            // the next stage's LDS-DMA is issued behind the fragment reads of the first half of the wave's MFMA groups:
-            // its issue cost (~100 cycles per instruction) hides under MFMAs instead of delaying the first fragment read,
-            // and the second half of the groups gives the data time to land before the closing barrier
+            // the DMA of the stage NS-1 blocks ahead is issued behind the fragment reads of the first half of the wave's
+            // MFMA groups: its issue cost (~100 cycles per instruction) hides under MFMAs
             if (more) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
-                    if ((q * SPREAD) / Q == i && wave + 8 * q < G) glds16(src[q] + ko, st + nxt + q * 8192);
+                    if ((q * SPREAD) / Q == i) glds16(src[q] + ko, st + nxt + dst[q]);
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
@@ -123,7 +134,12 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();   // waits for this wave's LDS-DMA (vmcnt(0)) and for every wave's reads of `cur`
+        // stage kb+1 must have landed (this wave's part) and every wave must be done reading stage kb before the next
+        // iteration overwrites it; in the tail (nothing issued this iteration) the queue is simply drained
+        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        nxt = cur;
+        cur = (cur + STAGE == NS * STAGE) ? 0 : cur + STAGE;
     }
 
     // ---- epilogue.  W rows are staged permuted (see the staging sources): within every 32-column block, MFMA tile
@@ -243,19 +259,19 @@ inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintp
 
 // ---- tile configurations ---------------------------------------------------------------------------------------------
 struct TileCfg {
-    int bn, bm;
+    int bn, bm, ns;
     void (*kernel)(SplitGemmArgs);
 };
-#define CLAVA_CFG(BN, BM, WN) {BN, BM, gemm_f16x3_kernel<BN, BM, WN>}
+#define CLAVA_CFG(BN, BM, WN, NS) {BN, BM, NS, gemm_f16x3_kernel<BN, BM, WN, NS>}
 const TileCfg kCfgs[] = {
-    CLAVA_CFG(256, 320, 2),   // 0: 144 KB LDS, 40 MFMA tiles per wave
-    CLAVA_CFG(128, 96, 4),    // 1: 128-wide layers at M = 20000 (209 tiles)
-    CLAVA_CFG(256, 160, 4),   // 2
-    CLAVA_CFG(256, 80, 8),    // 3
-    CLAVA_CFG(128, 320, 2),   // 4
-    CLAVA_CFG(128, 160, 4),   // 5
-    CLAVA_CFG(128, 80, 8),    // 6
-    CLAVA_CFG(64, 128, 2),    // 7: narrow outputs (heads, logits, the input gradient)
+    CLAVA_CFG(256, 320, 2, 2),   // 0: 144 KB LDS, 40 MFMA tiles per wave
+    CLAVA_CFG(128, 96, 4, 2),    // 1: 128-wide layers at M = 20000 (209 tiles)
+    CLAVA_CFG(256, 160, 4, 2),   // 2 (three stages fit in LDS but measured 15 % slower)
+    CLAVA_CFG(256, 80, 8, 2),    // 3
+    CLAVA_CFG(128, 320, 2, 2),   // 4
+    CLAVA_CFG(128, 160, 4, 2),   // 5
+    CLAVA_CFG(128, 80, 8, 2),    // 6
+    CLAVA_CFG(64, 128, 2, 2),    // 7: narrow outputs (heads, logits, the input gradient)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
@@ -299,7 +315,7 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     CLAVA_CHECK_ARG(cfg < kNumCfgs, "gemm_f16x3: tile configuration %d does not exist", cfg);
     if (cfg < 0) cfg = pick_cfg(g.M, g.N);
     const TileCfg& tc = kCfgs[cfg];
-    const int lds = 2 * (tc.bn + tc.bm) * 128;
+    const int lds = tc.ns * (tc.bn + tc.bm) * 128;
     if (!g_attr_set[cfg]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tc.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {

@@ -63,6 +63,31 @@ __global__ void __launch_bounds__(256) gmm_prep_kernel(const double* __restrict_
     if (threadIdx.x == 0) { s_mu2p[c] = part[0][0]; logdet[c] = part[1][0]; logw[c] = log(w[c]); }
 }
 
+// exp(x) for x <= 0 in the log-sum-exp of the responsibilities: round-to-nearest range reduction x = n ln2 + r,
+// |r| <= ln2 / 2, degree-11 Taylor polynomial in Horner form (truncation 0.347^12 / 12! = 6e-15 relative), exact scaling
+// by 2^n.  Branch-free, ~17 float64 instructions; the device library's exp() is ~3x that with branches, and with
+// 16 * ceil(k/16) of them per row the exponentials, not the matrix products, would set the kernel's speed.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -745.0);                                     // below this exp underflows to 0 anyway; keeps n in int range
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -6.93147180369123816490e-01, x);       // ln2 split hi / lo
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;                   // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);               // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);               // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);               // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);               // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);               // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);               // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);               // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);               // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);               // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 template <int CT>   // number of 16-component column tiles (1..4)
 __global__ void __launch_bounds__(256) gmm_estep_kernel(GmmArgs g) {
     __shared__ double Xs[ROWS * LDT];
@@ -136,7 +161,7 @@ __global__ void __launch_bounds__(256) gmm_estep_kernel(GmmArgs g) {
             }
             double sm = 0.0;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) sm += (ct * 16 + r < g.k) ? exp(wlp[ct] - mx) : 0.0;
+            for (int ct = 0; ct < CT; ++ct) sm += (ct * 16 + r < g.k) ? exp_nonpos(wlp[ct] - mx) : 0.0;
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
             const double lse = mx + log(sm);
@@ -155,6 +180,175 @@ __global__ void __launch_bounds__(256) gmm_estep_kernel(GmmArgs g) {
             }
         }
     }
+}
+
+
+// ---- resident-table kernel (the fast path) ---------------------------------------------------------------------------
+// Both k x d tables stay in LDS for the whole launch (staged once per workgroup, workgroups are persistent), each wave
+// owns 16-row tiles on its own (no workgroup barrier in the row loop) and loads its X operand straight from HBM into
+// MFMA registers: the contraction slot (ks, q) of a 32-column chunk is mapped to column 8*q + ks, so lane (row r,
+// q = lane >> 4) owns the 64 contiguous bytes X[r][j0 + 8q .. 8q + 7] (four 16-byte loads; the four q lanes of a row
+// cover its whole 256-byte segment).  The tables are staged in the matching order, piece-major
+// [chunk][tile][table][piece i][lane][2 doubles] so that a lane's B operands are conflict-free ds_read_b128s.
+// With X read once and nothing else streamed, the kernel is bound by the f64 matrix pipe for k > ~16 components
+// (4*N*d*16*ceil(k/16) FLOP) and by HBM below that.
+template <int CT, int NCH>   // 16-component column tiles (1..4), 32-column chunks held in registers per row tile (1, 2, 4)
+__global__ void __launch_bounds__(256) gmm_estep_resident_kernel(GmmArgs g, int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) double tab[];      // NCH * CT * 2 * 4 * 64 * 2 doubles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    // ---- stage the tables: element (chunk, ct, table, piece i, lane l, e) = table[ct*16 + (l & 15)][chunk*32 + 8*(l >> 4) + 2*i + e]
+    constexpr int TOTAL = NCH * CT * 2 * 4 * 64 * 2;
+    for (int s = tid; s < TOTAL; s += 256) {
+        const int e = s & 1, l = (s >> 1) & 63, i = (s >> 7) & 3, tb = (s >> 9) & 1;
+        const int ct = (s >> 10) % CT, ch = (s >> 10) / CT;
+        const int c = ct * 16 + (l & 15), col = ch * 32 + 8 * (l >> 4) + 2 * i + e;
+        double v = 0.0;
+        if (c < g.k && col < g.d) v = (tb ? g.P : g.mp)[(size_t)c * g.d + col];
+        tab[s] = v;
+    }
+    // per-component constants of this lane's columns, kept in registers: a load inside the row loop would queue behind
+    // the previous tile's log_resp stores on the in-order memory counter and expose their HBM latency once per use
+    double k_mu2p[CT], k_logdet[CT], k_logw[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = min(ct * 16 + r, g.k - 1);
+        k_mu2p[ct] = g.s_mu2p[c]; k_logdet[ct] = g.logdet[c]; k_logw[ct] = g.logw[c];
+    }
+    __syncthreads();
+
+    const long long n_tiles = (g.N + 15) / 16;
+    const long long stride = (long long)gridDim.x * 4;
+    double xa[NCH][8];
+    auto load_tile = [&](long long tile) {
+        const long long row_ld = min(tile * 16 + r, g.N - 1);
+        const double* xrow = g.X + row_ld * g.ldx + 8 * q;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c0 = ch * 32 + 8 * q;
+            if (vec_ok && c0 + 8 <= g.d) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double2 v = *reinterpret_cast<const double2*>(xrow + ch * 32 + 2 * i);
+                    xa[ch][2 * i] = v.x; xa[ch][2 * i + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xa[ch][i] = (c0 + i < g.d) ? xrow[ch * 32 + i] : 0.0;
+            }
+        }
+    };
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile < n_tiles) load_tile(tile);
+    for (; tile < n_tiles; tile += stride) {
+        f64x4 acc1[CT], acc2[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { acc1[ct] = {0.0, 0.0, 0.0, 0.0}; acc2[ct] = {0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const double* tch = tab + (size_t)ch * CT * 2 * 4 * 64 * 2 + lane * 2;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                double b1[8], b2[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double2 m = *reinterpret_cast<const double2*>(tch + ((ct * 2 + 0) * 4 + i) * 128);
+                    const double2 p = *reinterpret_cast<const double2*>(tch + ((ct * 2 + 1) * 4 + i) * 128);
+                    b1[2 * i] = m.x; b1[2 * i + 1] = m.y;
+                    b2[2 * i] = p.x; b2[2 * i + 1] = p.y;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ch][ks], b1[ks], acc1[ct], 0, 0, 0);
+                    acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ch][ks] * xa[ch][ks], b2[ks], acc2[ct], 0, 0, 0);
+                }
+            }
+        }
+        // the next tile's X is requested now and must have landed before this tile's stores are issued (below): the wait
+        // then never includes store completions, and the stores drain under the next tile's matrix products
+        if (tile + stride < n_tiles) load_tile(tile + stride);
+        // epilogue.  f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+        double out_resp[4][CT], out_lse[4];
+        int out_arg[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            double wlp[CT];
+            double mx = -INFINITY;
+            int arg = 0x7fffffff;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + r;
+                if (c < g.k) {
+                    const double lp = (k_mu2p[ct] - 2.0 * acc1[ct][reg]) + acc2[ct][reg];
+                    wlp[ct] = ((-0.5 * (g.dln2pi + lp)) + k_logdet[ct]) + k_logw[ct];
+                } else {
+                    wlp[ct] = -INFINITY;
+                }
+                if (wlp[ct] > mx) { mx = wlp[ct]; arg = c; }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const double om = __shfl_xor(mx, o, 64);
+                const int oa = __shfl_xor(arg, o, 64);
+                if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+            }
+            double sm = 0.0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) sm += (ct * 16 + r < g.k) ? exp_nonpos(wlp[ct] - mx) : 0.0;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            const double lse = mx + log(sm);
+            out_lse[reg] = lse; out_arg[reg] = arg;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) out_resp[reg][ct] = wlp[ct] - lse;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long long row = tile * 16 + q + 4 * reg;
+            if (row < g.N) {
+                if (r == 0) {
+                    g.log_prob_norm[row] = out_lse[reg];
+                    if (g.labels) g.labels[row] = out_arg[reg];
+                }
+                if (g.log_resp) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int c = ct * 16 + r;
+                        if (c < g.k) g.log_resp[row * g.k + c] = out_resp[reg][ct];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CT, int NCH>
+int launch_resident(const GmmArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr int lds_bytes = NCH * CT * 2 * 4 * 64 * 2 * 8;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_estep_resident_kernel<CT, NCH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;
+        }
+        attr_set = true;
+    }
+    const long long n_tiles = (g.N + 15) / 16;
+    const int per_cu = lds_bytes <= 40 * 1024 ? 4 : (lds_bytes <= 80 * 1024 ? 2 : 1);     // co-resident workgroups per CU
+    long long grid = (n_tiles + 3) / 4;
+    if (grid > 256LL * per_cu) grid = 256LL * per_cu;
+    const int vec_ok = ((g.ldx & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.X) & 15) == 0);
+    hipLaunchKernelGGL((gmm_estep_resident_kernel<CT, NCH>), dim3((unsigned)grid), dim3(256), lds_bytes, st, g, vec_ok);
+    return 0;
+}
+
+template <int CT>
+int launch_resident_ct(const GmmArgs& g, int n_chunks, hipStream_t st) {
+    if (n_chunks <= 1) return launch_resident<CT, 1>(g, st);
+    if (n_chunks <= 2) return launch_resident<CT, 2>(g, st);
+    return launch_resident<CT, 4>(g, st);
 }
 
 }  // namespace
@@ -191,6 +385,22 @@ int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int 
     // algorithmic traffic: X once, log_resp + log_prob_norm (+ labels) once; flops: two N x d x k products
     ProfScope prof(PROF_GMM, 4.0 * N * d * k, 8.0 * N * (d + (log_resp ? k : 0) + 1) + (labels ? 4.0 * N : 0.0), st);
     const int ct = (k + 15) / 16;
+    // resident-table fast path for d <= 128 (up to four 32-column chunks of a row tile held in registers, both tables
+    // in <= 128 KB of LDS); wider tables take the chunk-staging kernel
+    const int n_chunks = (d + 31) / 32;
+    if (n_chunks <= 4) {
+        int bad = 1;
+        switch (ct) {
+            case 1: bad = launch_resident_ct<1>(g, n_chunks, st); break;
+            case 2: bad = launch_resident_ct<2>(g, n_chunks, st); break;
+            case 3: bad = launch_resident_ct<3>(g, n_chunks, st); break;
+            default: bad = launch_resident_ct<4>(g, n_chunks, st); break;
+        }
+        if (!bad) {
+            CLAVA_CHECK_LAUNCH("clava_gmm_estep_f64");
+            return CLAVA_OK;
+        }
+    }
     switch (ct) {
         case 1: hipLaunchKernelGGL((gmm_estep_kernel<1>), dim3(grid), dim3(256), 0, st, g); break;
         case 2: hipLaunchKernelGGL((gmm_estep_kernel<2>), dim3(grid), dim3(256), 0, st, g); break;

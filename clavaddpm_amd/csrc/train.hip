@@ -165,20 +165,48 @@ __global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ v, 
     if (threadIdx.x == 0) out[0] = part[0] * scale;
 }
 
-// db_slabs[s][n] = sum over the s-th batch range of dy[:, n]: bias gradients, same split scheme as the weight slabs
+// db_slabs[s][n] = sum over the s-th batch range of dy[:, n]: bias gradients, same split scheme as the weight slabs.
+// One workgroup owns 32 columns of one batch range: 8 column groups (one float4 each) x 32 row lanes; every thread sums
+// its rows with four independent accumulators, the 32 row lanes are combined through LDS in a fixed order (bitwise
+// reproducible, no atomics).  HBM-bound: 4*M*N bytes.
+template <bool VEC>
 __global__ void __launch_bounds__(256) colsum_slabs_kernel(const float* __restrict__ dy, int ld, int M, int N, int splits,
                                                            float* __restrict__ slabs, long long slab_stride) {
-    __shared__ float part[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    __shared__ float part[32][33];
+    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;       // column group, row lane
+    const int col = blockIdx.x * 32 + cg * 4;
     const int rows_per = (M + splits - 1) / splits;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float acc = 0.f;
-    if (col < N)
-        for (int r = r0 + q; r < r1; r += 4) acc += dy[(size_t)r * ld + col];
-    part[q][threadIdx.x & 63] = acc;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+        if (col < N) {                                           // N % 4 == 0 here: the whole float4 is in range
+            int r = r0 + q;
+            for (; r + 32 < r1; r += 64) {
+                const float4 u = *reinterpret_cast<const float4*>(dy + (size_t)r * ld + col);
+                const float4 v = *reinterpret_cast<const float4*>(dy + (size_t)(r + 32) * ld + col);
+                a0[0] += u.x; a0[1] += u.y; a0[2] += u.z; a0[3] += u.w;
+                a1[0] += v.x; a1[1] += v.y; a1[2] += v.z; a1[3] += v.w;
+            }
+            if (r < r1) {
+                const float4 u = *reinterpret_cast<const float4*>(dy + (size_t)r * ld + col);
+                a0[0] += u.x; a0[1] += u.y; a0[2] += u.z; a0[3] += u.w;
+            }
+        }
+    } else {
+        for (int r = r0 + q; r < r1; r += 32)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (col + c < N) a0[c] += dy[(size_t)r * ld + col + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[q][cg * 4 + c] = a0[c] + a1[c];
     __syncthreads();
-    if (q == 0 && col < N)
-        slabs[(size_t)blockIdx.y * slab_stride + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 32 && blockIdx.x * 32 + threadIdx.x < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
+        slabs[(size_t)blockIdx.y * slab_stride + blockIdx.x * 32 + threadIdx.x] = t;
+    }
 }
 
 // out[i] = scale * sum_s slabs[s][i]
@@ -287,8 +315,13 @@ int clava_colsum_slabs_f32(const float* dy, int lddy, int M, int N, int splits, 
                            void* stream) {
     CLAVA_CHECK_ARG(dy && db_slabs && M > 0 && N > 0 && splits >= 1 && splits <= 64 && lddy >= N, "colsum_slabs: bad arguments");
     ProfScope prof(PROF_MISC, 0.0, 4.0 * M * N, (hipStream_t)stream);
-    hipLaunchKernelGGL(colsum_slabs_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, dy, lddy, M, N, splits,
-                       db_slabs, slab_stride);
+    const bool vec = (N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(colsum_slabs_kernel<true>, dim3((N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy, lddy, M, N,
+                           splits, db_slabs, slab_stride);
+    else
+        hipLaunchKernelGGL(colsum_slabs_kernel<false>, dim3((N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy, lddy, M, N,
+                           splits, db_slabs, slab_stride);
     CLAVA_CHECK_LAUNCH("clava_colsum_slabs_f32");
     return CLAVA_OK;
 }
