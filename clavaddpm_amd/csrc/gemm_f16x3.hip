@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) glds16(src[q] + ko, st + s0 * STAGE + dst[q]);
     }
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
+    if constexpr (NS == 2) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
 
     int cur = 0, nxt = (NS - 1) * STAGE;                     // byte offsets of the stage read now / filled now
     for (int kb = 0; kb < nkb; ++kb) {
@@ -136,8 +137,12 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         }
         // stage kb+1 must have landed (this wave's part) and every wave must be done reading stage kb before the next
         // iteration overwrites it; in the tail (nothing issued this iteration) the queue is simply drained
-        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (NS == 2) {
+            __syncthreads();      // two stages: the whole DMA queue is this stage; the compiler keeps rotating MFMAs across it
+        } else {
+            if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         nxt = cur;
         cur = (cur + STAGE == NS * STAGE) ? 0 : cur + STAGE;
     }
@@ -275,7 +280,7 @@ const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
-bool g_attr_set[kNumCfgs] = {};
+bool g_attr_set[64][kNumCfgs] = {};   // per device: the LDS limit is a per-device function attribute
 
 // cost model (arbitrary units, calibrated on MI355X with tools/bench_f16x3.py): rounds of 256 workgroups x per-k-block
 // time of one tile, the larger of its MFMA time and its LDS-fill time
@@ -316,13 +321,15 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     if (cfg < 0) cfg = pick_cfg(g.M, g.N);
     const TileCfg& tc = kCfgs[cfg];
     const int lds = tc.ns * (tc.bn + tc.bm) * 128;
-    if (!g_attr_set[cfg]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!g_attr_set[dev][cfg]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tc.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             clava_set_error("gemm_f16x3: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
             return CLAVA_ERR_LAUNCH;
         }
-        g_attr_set[cfg] = true;
+        g_attr_set[dev][cfg] = true;
     }
     g.tiles_m = (g.M + tc.bm - 1) / tc.bm;
     g.tiles_n = (g.N + tc.bn - 1) / tc.bn;

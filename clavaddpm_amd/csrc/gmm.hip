@@ -325,15 +325,17 @@ __global__ void __launch_bounds__(256) gmm_estep_resident_kernel(GmmArgs g, int 
 
 template <int CT, int NCH>
 int launch_resident(const GmmArgs& g, hipStream_t st) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {};   // per device
     constexpr int lds_bytes = NCH * CT * 2 * 4 * 64 * 2 * 8;
-    if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_estep_resident_kernel<CT, NCH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
         }
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const long long n_tiles = (g.N + 15) / 16;
     const int per_cu = lds_bytes <= 40 * 1024 ? 4 : (lds_bytes <= 80 * 1024 ? 2 : 1);     // co-resident workgroups per CU
