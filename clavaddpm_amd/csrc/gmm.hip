@@ -219,8 +219,8 @@ __global__ void __launch_bounds__(256) gmm_estep_resident_kernel(GmmArgs g, int 
 
     const long long n_tiles = (g.N + 15) / 16;
     const long long stride = (long long)gridDim.x * 4;
-    double xa[NCH][8];
-    auto load_tile = [&](long long tile) {
+    double xa[NCH][8], xb[NCH][8];
+    auto load_tile = [&](long long tile, double (&dst)[NCH][8]) {
         const long long row_ld = min(tile * 16 + r, g.N - 1);
         const double* xrow = g.X + row_ld * g.ldx + 8 * q;
 #pragma unroll
@@ -230,17 +230,21 @@ __global__ void __launch_bounds__(256) gmm_estep_resident_kernel(GmmArgs g, int 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const double2 v = *reinterpret_cast<const double2*>(xrow + ch * 32 + 2 * i);
-                    xa[ch][2 * i] = v.x; xa[ch][2 * i + 1] = v.y;
+                    dst[ch][2 * i] = v.x; dst[ch][2 * i + 1] = v.y;
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xa[ch][i] = (c0 + i < g.d) ? xrow[ch * 32 + i] : 0.0;
+                for (int i = 0; i < 8; ++i) dst[ch][i] = (c0 + i < g.d) ? xrow[ch * 32 + i] : 0.0;
             }
         }
     };
     long long tile = (long long)blockIdx.x * 4 + wave;
-    if (tile < n_tiles) load_tile(tile);
+    if (tile < n_tiles) load_tile(tile, xa);
     for (; tile < n_tiles; tile += stride) {
+        // the next tile's X is requested before this tile's matrix products and has landed by the time this tile's stores
+        // are issued: the wait for it (below) never includes store completions, and the stores drain under the next
+        // tile's products
+        load_tile(min(tile + stride, n_tiles - 1), xb);
         f64x4 acc1[CT], acc2[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { acc1[ct] = {0.0, 0.0, 0.0, 0.0}; acc2[ct] = {0.0, 0.0, 0.0, 0.0}; }
@@ -264,14 +268,15 @@ __global__ void __launch_bounds__(256) gmm_estep_resident_kernel(GmmArgs g, int 
                 }
             }
         }
-        // the next tile's X is requested now and must have landed before this tile's stores are issued (below): the wait
-        // then never includes store completions, and the stores drain under the next tile's matrix products
-        if (tile + stride < n_tiles) load_tile(tile + stride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // xb has landed; nothing else is in flight but old stores
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xa[ch][i] = xb[ch][i];
         // epilogue.  f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
-        double out_resp[4][CT], out_lse[4];
-        int out_arg[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+            const long long row = tile * 16 + q + 4 * reg;
             double wlp[CT];
             double mx = -INFINITY;
             int arg = 0x7fffffff;
@@ -298,24 +303,16 @@ __global__ void __launch_bounds__(256) gmm_estep_resident_kernel(GmmArgs g, int 
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
             const double lse = mx + log(sm);
-            out_lse[reg] = lse; out_arg[reg] = arg;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) out_resp[reg][ct] = wlp[ct] - lse;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const long long row = tile * 16 + q + 4 * reg;
             if (row < g.N) {
                 if (r == 0) {
-                    g.log_prob_norm[row] = out_lse[reg];
-                    if (g.labels) g.labels[row] = out_arg[reg];
+                    g.log_prob_norm[row] = lse;
+                    if (g.labels) g.labels[row] = arg;
                 }
                 if (g.log_resp) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         const int c = ct * 16 + r;
-                        if (c < g.k) g.log_resp[row * g.k + c] = out_resp[reg][ct];
+                        if (c < g.k) g.log_resp[row * g.k + c] = wlp[ct] - lse;
                     }
                 }
             }
