@@ -145,6 +145,11 @@ int clava_split_pack_f32(const float* src, long long ld, long long rows, int col
     return clava_launch_split_pack(src, ld, rows, cols, shift, (char*)dst, pitch, overflow, (hipStream_t)stream);
 }
 
+int clava_split_pack_transposed_f32(const float* src, long long ld, long long rows, int cols, int shift, void* dst, long long pitch,
+                                    int* overflow, void* stream) {
+    return clava_launch_split_pack(src, ld, rows, cols, shift, (char*)dst, pitch, overflow, (hipStream_t)stream, true);
+}
+
 int clava_split_unpack_f32(const void* src, long long pitch, long long rows, int cols, int shift, float* dst, long long ld,
                            void* stream) {
     return clava_launch_split_unpack((const char*)src, pitch, rows, cols, shift, dst, ld, (hipStream_t)stream);

@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
 }
 
 // float32 [rows][cols] (ld) -> split rows; one thread per 4 consecutive columns
-__global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict__ src, long long ld, long long rows, int cols,
+// element (row, col) of the source is src[row * sr + col * sc]: (ld, 1) packs a matrix as it stands, (1, ld) its transpose
+__global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict__ src, long long sr, long long sc, long long rows, int cols,
                                                          int groups, float scale, char* __restrict__ dst, long long pitch,
                                                          int* overflow) {
     const long long total = rows * groups;
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict
         h4 hi, lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float s = (c0 + r < cols) ? src[row * ld + c0 + r] * scale : 0.f;
+            const float s = (c0 + r < cols) ? src[row * sr + (c0 + r) * sc] * scale : 0.f;
             ovf |= !(fabsf(s) <= 65504.f);
             hi[r] = (_Float16)s;
             lo[r] = (_Float16)(s - (float)hi[r]);
@@ -282,19 +283,22 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
 bool g_attr_set[64][kNumCfgs] = {};   // per device: the LDS limit is a per-device function attribute
 
-// cost model (arbitrary units, calibrated on MI355X with tools/bench_f16x3.py): rounds of 256 workgroups x per-k-block
-// time of one tile, the larger of its MFMA time and its LDS-fill time
-int pick_cfg(int M, int N) {
+// Cost model, calibrated on MI355X with tools/bench_f16x3.py: a configuration's sustained rate on a full chip (TFLOP/s
+// algorithmic, K = 1024, M = 20000), the tiles of the most loaded CU run back to back, plus a fixed launch / prologue /
+// epilogue cost.  It reproduces the measured times of the sampling (M = 20000) and training (M = 4096) shapes to ~15 %.
+const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0};
+static_assert(sizeof(kRateTF) / sizeof(kRateTF[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one rate per configuration");
+
+int pick_cfg(int M, int N, int Kp) {
     int best = kNumCfgs - 1;
     double best_cost = 1e300;
     for (int c = 0; c < kNumCfgs; ++c) {
         const int bn = kCfgs[c].bn, bm = kCfgs[c].bm;
         if (bn > 64 && N <= bn / 2) continue;
         const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        const double rounds = (double)((tiles + 255) / 256);
-        const double mfma = (double)bn * bm * 3.0 / 64.0;          // cycles per k block on 4 SIMDs
-        const double fill = (bn + bm) * 128.0 / 48.0;              // cycles per k block at ~48 B/clk/CU from L2
-        const double cost = rounds * ((mfma > fill ? mfma : fill) + 300.0);
+        const double per_cu = (double)((tiles + 255) / 256);
+        const double tile_us = 2.0 * bn * bm * (double)Kp / (kRateTF[c] * 1e6 / 256.0);
+        const double cost = per_cu * tile_us + 5.0;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return best;
@@ -318,7 +322,7 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     CLAVA_CHECK_ARG(!g.out_f32 || g.ldc >= g.N, "gemm_f16x3: ldc too small");
     CLAVA_CHECK_ARG(g.act == CLAVA_ACT_NONE || g.act == CLAVA_ACT_RELU || g.act == CLAVA_ACT_LEAKY, "gemm_f16x3: activation %d", g.act);
     CLAVA_CHECK_ARG(cfg < kNumCfgs, "gemm_f16x3: tile configuration %d does not exist", cfg);
-    if (cfg < 0) cfg = pick_cfg(g.M, g.N);
+    if (cfg < 0) cfg = pick_cfg(g.M, g.N, g.Kp);
     const TileCfg& tc = kCfgs[cfg];
     const int lds = tc.ns * (tc.bn + tc.bm) * 128;
     int dev = 0;
@@ -342,8 +346,8 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
 }
 
 int clava_launch_split_pack(const float* src, long long ld, long long rows, int cols, int shift, char* dst,
-                            long long pitch, int* overflow, hipStream_t stream) {
-    CLAVA_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld >= cols, "split_pack: bad arguments");
+                            long long pitch, int* overflow, hipStream_t stream, bool transposed) {
+    CLAVA_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld >= (transposed ? rows : (long long)cols), "split_pack: bad arguments");
     const int Kp = (cols + 31) & ~31;
     CLAVA_CHECK_ARG(pitch >= 4LL * Kp && pitch % 8 == 0 && aligned(dst, 8), "split_pack: pitch %lld too small or misaligned", pitch);
     CLAVA_CHECK_ARG(shift >= -24 && shift <= 24, "split_pack: shift %d out of range", shift);
@@ -351,8 +355,8 @@ int clava_launch_split_pack(const float* src, long long ld, long long rows, int 
     const long long total = rows * groups;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     ProfScope prof(PROF_MISC, 0.0, 8.0 * rows * Kp, stream);
-    hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, ld, rows, cols, groups, ldexpf(1.f, shift), dst,
-                       pitch, overflow);
+    hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, transposed ? 1LL : ld, transposed ? ld : 1LL, rows, cols,
+                       groups, ldexpf(1.f, shift), dst, pitch, overflow);
     CLAVA_CHECK_LAUNCH("clava_split_pack");
     return CLAVA_OK;
 }

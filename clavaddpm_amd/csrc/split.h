@@ -42,7 +42,8 @@ struct SplitGemmArgs {
 // cfg < 0: pick the tile configuration for the shape; otherwise force configuration `cfg` (tools/bench_f16x3.py)
 int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream);
 int clava_gemm_f16x3_config_count();
+// transposed: the packed matrix [rows, cols] is the transpose of the stored one (element (r, c) = src[c * ld + r])
 int clava_launch_split_pack(const float* src, long long ld, long long rows, int cols, int shift, char* dst,
-                            long long pitch, int* overflow, hipStream_t stream);
+                            long long pitch, int* overflow, hipStream_t stream, bool transposed = false);
 int clava_launch_split_unpack(const char* src, long long pitch, long long rows, int cols, int shift, float* dst,
                               long long ld, hipStream_t stream);

@@ -115,15 +115,38 @@ def overflow_flag(device):
     return torch.zeros(1, device=device, dtype=torch.int32)
 
 
-def split_pack(x, shift=0, overflow=None):
-    """float32 [rows, cols] -> SplitTensor (clava_split_pack_f32)."""
+def split_pack(x, shift=0, overflow=None, out=None):
+    """float32 [rows, cols] -> SplitTensor (clava_split_pack_f32); `out` reuses a SplitTensor of the same shape."""
     require_cuda(x)
     x = _f32c(x, "x")
     rows, cols = x.shape
-    out = split_empty(rows, cols, shift, x.device)
+    if out is None:
+        out = split_empty(rows, cols, shift, x.device)
+    else:
+        if (out.rows, out.cols) != (rows, cols):
+            raise _lib.ClavaHipError("split_pack: `out` has another shape")
+        out.shift = shift
     if rows:
         check(lib().clava_split_pack_f32(ptr(x), _lib.c_long(x.stride(0)), _lib.c_long(rows), c_int(cols), c_int(shift),
                                          ptr(out.buf), _lib.c_long(out.pitch), ptr(overflow), stream_ptr()), "clava_split_pack_f32")
+    return out
+
+
+def split_pack_transposed(x, shift=0, overflow=None, out=None):
+    """SplitTensor of x.T for a float32 [cols, rows] matrix x, without materialising the transpose."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    cols, rows = x.shape
+    if out is None:
+        out = split_empty(rows, cols, shift, x.device)
+    else:
+        if (out.rows, out.cols) != (rows, cols):
+            raise _lib.ClavaHipError("split_pack_transposed: `out` has another shape")
+        out.shift = shift
+    if rows:
+        check(lib().clava_split_pack_transposed_f32(ptr(x), _lib.c_long(x.stride(0)), _lib.c_long(rows), c_int(cols), c_int(shift),
+                                                    ptr(out.buf), _lib.c_long(out.pitch), ptr(overflow), stream_ptr()),
+              "clava_split_pack_transposed_f32")
     return out
 
 
@@ -136,18 +159,26 @@ def split_unpack(s):
 
 
 def linear_f16x3(x, w, bias=None, act=None, rowadd=None, act_out=None, slope=0.0, alpha=1.0, out_shift=None, out_f32=False,
-                 overflow=None, tile_config=-1, out=None):
+                 overflow=None, tile_config=-1, out=None, both=False, out2=None):
     """alpha * act'(act_out) * act(x @ w.T + bias + rowadd) with x, w SplitTensors (clava_gemm_f16x3).
-    Returns a SplitTensor with shift `out_shift`, or a float32 tensor when out_f32."""
+    Returns a SplitTensor with shift `out_shift`, or a float32 tensor when out_f32, or (SplitTensor, float32) when `both`
+    (`out` = the SplitTensor to fill, `out2` = the float32 tensor to fill)."""
     M, K = x.rows, x.cols
     N = w.rows
     if w.cols != K:
         raise _lib.ClavaHipError(f"linear_f16x3: x is [{M},{K}] but w is [{w.rows},{w.cols}]")
     y_split = y_f32 = None
-    if out_f32:
+    if both:
+        y_split = out if out is not None else split_empty(M, N, 0 if out_shift is None else out_shift, x.buf.device)
+        if out is not None and out_shift is not None:
+            y_split.shift = out_shift
+        y_f32 = out2 if out2 is not None else torch.empty((M, N), device=x.buf.device, dtype=torch.float32)
+    elif out_f32:
         y_f32 = out if out is not None else torch.empty((M, N), device=x.buf.device, dtype=torch.float32)
     else:
         y_split = out if out is not None else split_empty(M, N, 0 if out_shift is None else out_shift, x.buf.device)
+        if out is not None and out_shift is not None:
+            y_split.shift = out_shift
     check(lib().clava_gemm_f16x3(ptr(x.buf), _lib.c_long(x.pitch), c_int(x.shift), ptr(w.buf), _lib.c_long(w.pitch), c_int(w.shift),
                                  ptr(_f32c(bias, "bias")), ptr(_f32c(rowadd, "rowadd")), c_int(_ACT[act]),
                                  ptr(act_out.buf) if act_out is not None else None,
@@ -157,4 +188,6 @@ def linear_f16x3(x, w, bias=None, act=None, rowadd=None, act_out=None, slope=0.0
                                  c_int(y_split.shift if y_split is not None else 0), ptr(y_f32),
                                  c_int(y_f32.stride(0) if y_f32 is not None else 0), c_int(M), c_int(N), c_int(K), ptr(overflow),
                                  c_int(tile_config), stream_ptr()), "clava_gemm_f16x3")
+    if both:
+        return y_split, y_f32
     return y_f32 if out_f32 else y_split

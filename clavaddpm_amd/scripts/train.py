@@ -84,6 +84,15 @@ class Trainer:
             p.data = p.data.clone()
         self._flattened = False
 
+    def _split_state(self):
+        """The split-f16 state when that layer-kernel family is selected and the stack has hidden blocks to run on it."""
+        from .. import split_nets
+        if split_nets.get_gemm_mode() != "f16x3" or len(self.diffusion._denoise_fn.mlp.blocks) < 2:
+            return None
+        if getattr(self, "_split", None) is None:
+            self._split = _tr.SplitTrainState()
+        return self._split
+
     def _anneal_lr(self, step):
         frac_done = step / self.steps
         self.lr = self.init_lr * (1 - frac_done)
@@ -100,9 +109,19 @@ class Trainer:
         x = x.to(self.device)
         t, noise, u, seed = _tr.draw(d, x, draws)
         x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
-        model_out, saved = _tr.denoiser_forward(net, x_in, t)
-        loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
-        _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs)
+        st = self._split_state()
+        if st is None or st.due():
+            # float32 step (always when CLAVA_GEMM=f32; every `period`-th step otherwise, to re-fix the plane scales)
+            model_out, saved = _tr.denoiser_forward(net, x_in, t)
+            loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+            gs = [None] * len(saved[4]) if st is not None else None
+            _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs, collect=gs)
+            if st is not None:
+                st.calibrate(net.stack()[0], saved[4], gs)
+        else:
+            model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
+            loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+            _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)

@@ -78,7 +78,7 @@ def denoiser_forward(net, x_in, t):
     return hs[-1], (x_in, te, z1, a1, hs)
 
 
-def denoiser_backward(net, saved, d_out, layout, slabs, splits=GRAD_SPLITS, want_dx=False):
+def denoiser_backward(net, saved, d_out, layout, slabs, splits=GRAD_SPLITS, want_dx=False, collect=None):
     """Backward through the denoiser: fills `slabs` [splits, layout.total] with partial parameter gradients
     (weight slabs from clava_gemm_wgrad_f32, bias slabs from clava_colsum_slabs_f32); returns dx or None."""
     x_in, te, z1, a1, hs = saved
@@ -103,6 +103,8 @@ def denoiser_backward(net, saved, d_out, layout, slabs, splits=GRAD_SPLITS, want
         param_grads(names[l], g, hs[l - 1])
         # input gradient, with ReLU' of the previous block folded in (layer 0 = proj has no activation)
         g = ops.linear_dgrad(g, ws[l].detach(), act_out=hs[l - 1] if l - 1 >= 1 else None, slope=0.0)
+        if collect is not None:
+            collect[l - 1] = g                  # gradient w.r.t. the pre-activation of layer l-1
     param_grads("proj", g, x_in)
     # time-embedding branch: emb was added to proj's output, so d emb = g
     param_grads("time_embed.2", g, a1)
@@ -111,6 +113,128 @@ def denoiser_backward(net, saved, d_out, layout, slabs, splits=GRAD_SPLITS, want
     param_grads("time_embed.0", d_z1, te)
     if want_dx:
         return ops.linear_dgrad(g, ws[0].detach())
+    return None
+
+
+# ------------------------------------------------------------------------- split-f16 forward / input gradients
+class SplitTrainState:
+    """State of the split-f16 training path of one Trainer (csrc/split.h): the hidden blocks' forward products and
+    their input-gradient products run on the f16 matrix cores at float32-level accuracy; weight gradients, the 2- and
+    D_in-wide end layers and the time-embedding branch stay on the float32-input MFMA kernels.
+
+    Weights change every step, so they are re-packed every step (17 MB).  The power-of-two plane scales are taken from
+    a float32 step: every `period`-th step runs entirely on the float32 kernels and records the largest magnitude of
+    every weight, activation and gradient tensor; scales place those near 2^6 (activations, gradients) / 2^10
+    (weights), i.e. a factor 1000 / 64 below the float16 limit, far more than anything moves in `period` steps at
+    training learning rates.  The device overflow flag is read at the same cadence; a raised flag is an error."""
+
+    def __init__(self, period=50):
+        self.period = period
+        self.shift_h = self.shift_g = self.shift_w = None
+        self.flag = None
+        self.steps_since = None
+        self.bufs = {}
+
+    def due(self):
+        return self.shift_h is None or self.steps_since >= self.period
+
+    def buf(self, key, rows, cols, device):
+        b = self.bufs.get(key)
+        if b is None or (b.rows, b.cols) != (rows, cols):
+            b = ops.split_empty(rows, cols, 0, device)
+            self.bufs[key] = b
+        return b
+
+    def calibrate(self, ws, hs, gs):
+        """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step."""
+        from .split_nets import TARGET_LOG2, shift_for
+        n = len(ws)
+        if self.flag is None:
+            self.flag = torch.zeros(1, device=ws[0].device, dtype=torch.int32)
+        elif int(self.flag.item()) != 0:
+            raise _lib.ClavaHipError("split-f16 training: a tensor left the float16 range since the last calibration "
+                                     "(magnitudes grew by more than 60x within %d steps)" % self.period)
+        stats = torch.stack([w.detach().abs().max() for w in ws] + [h.abs().max() for h in hs] +
+                            [gs[l].abs().max() if gs[l] is not None else torch.zeros((), device=ws[0].device) for l in range(n)])
+        v = stats.cpu().tolist()
+        self.shift_w = [shift_for(x, 10) for x in v[:n]]
+        self.shift_h = [shift_for(x, TARGET_LOG2) for x in v[n:2 * n]]
+        self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:]]
+        self.steps_since = 0
+
+
+def denoiser_forward_split(net, x_in, t, st):
+    """`denoiser_forward` with the hidden blocks (layers 1 .. n-2 of the stack) on clava_gemm_f16x3."""
+    te = timestep_embedding(t, net.dim_t)
+    w0, b0 = net.time_embed[0].weight.detach(), net.time_embed[0].bias.detach()
+    w2, b2 = net.time_embed[2].weight.detach(), net.time_embed[2].bias.detach()
+    z1 = ops.linear(te, w0, b0)
+    a1 = _silu(z1)
+    emb = ops.linear(a1, w2, b2)
+    ws, bs, acts = net.stack()
+    n = len(ws)
+    dev = x_in.device
+    B = x_in.shape[0]
+    h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)            # proj(x) + emb (modules.py:459), float32
+    hs = [h]
+    hsplit = [ops.split_pack(h, st.shift_h[0], st.flag, out=st.buf(("h", 0), B, h.shape[1], dev))]
+    wsp = []
+    for l in range(1, n - 1):
+        w = ws[l].detach()
+        wsp.append(ops.split_pack(w, st.shift_w[l], st.flag, out=st.buf(("w", l), w.shape[0], w.shape[1], dev)))
+        last = l == n - 2
+        if last:                                  # the head reads float32: no split copy of the last hidden activation
+            hf = ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", out_f32=True, overflow=st.flag)
+            hsplit.append(None)
+        else:
+            hsp, hf = ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", both=True, out_shift=st.shift_h[l],
+                                       out=st.buf(("h", l), B, w.shape[0], dev), overflow=st.flag)
+            hsplit.append(hsp)
+        hs.append(hf)
+    out = ops.linear(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
+    hs.append(out)
+    return out, (x_in, te, z1, a1, hs, hsplit)
+
+
+def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS):
+    """`denoiser_backward` with the input-gradient products of layers n-2 .. 1 on clava_gemm_f16x3 (weight and bias
+    gradients on the float32 kernels from the float32 copies every split product also writes)."""
+    x_in, te, z1, a1, hs, hsplit = saved
+    total = layout.total
+    M = d_out.shape[0]
+    dev = d_out.device
+
+    def param_grads(prefix, dy, inp):
+        wi = layout.index[prefix + ".weight"]
+        n_out, k_in = layout.shapes[wi]
+        ops.linear_wgrad(dy, inp, splits=splits, out=slabs[:, layout.offsets[wi]:], slab_stride=total)
+        bi = layout.index[prefix + ".bias"]
+        check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(M), c_int(n_out), c_int(splits),
+                                           ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
+
+    n_blocks = len(net.mlp.blocks)
+    names = ["proj"] + [f"mlp.blocks.{i}.linear" for i in range(n_blocks)] + ["mlp.head"]
+    ws, _, _ = net.stack()
+    n = len(ws)
+    # head (float32): parameter gradients and the gradient w.r.t. the last hidden pre-activation
+    param_grads(names[n - 1], d_out, hs[n - 2])
+    g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
+    gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
+    for l in range(n - 2, 0, -1):
+        param_grads(names[l], g, hs[l - 1])
+        w = ws[l].detach()
+        wt = ops.split_pack_transposed(w, st.shift_w[l], st.flag, out=st.buf(("wt", l), w.shape[1], w.shape[0], dev))
+        if l - 1 >= 1:
+            gs, g = ops.linear_f16x3(gs, wt, act_out=hsplit[l - 1], slope=0.0, both=True, out_shift=st.shift_g[l - 1],
+                                     out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)
+        else:                                     # layer 0 = proj has no activation; only the float32 gradient is needed
+            g = ops.linear_f16x3(gs, wt, out_f32=True, overflow=st.flag)
+    param_grads("proj", g, x_in)
+    param_grads("time_embed.2", g, a1)
+    d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
+    d_z1 = _silu_backward(z1, d_a1)
+    param_grads("time_embed.0", d_z1, te)
+    st.steps_since += 1
     return None
 
 

@@ -83,6 +83,10 @@ int clava_split_pack_f32(const float* src, long long ld, long long rows, int col
                          int* overflow, void* stream);
 int clava_split_unpack_f32(const void* src, long long pitch, long long rows, int cols, int shift, float* dst, long long ld,
                            void* stream);
+/* packs the TRANSPOSE of a stored matrix: dst[rows, cols] with element (r, c) = src[c * ld + r] (an nn.Linear weight as the
+ * operand of the input-gradient product dy . W, scripts/train.py:37). */
+int clava_split_pack_transposed_f32(const float* src, long long ld, long long rows, int cols, int shift, void* dst,
+                                    long long pitch, int* overflow, void* stream);
 
 /* y[M,N] = alpha * act'(act_out)[M,N] * act( x[M,K] . w[N,K]^T + bias[N] + rowadd[N] )
  * x, w: split rows with shifts shift_x, shift_w; y_split (shift_y) and/or y_f32 (ldy) receive the result; act_out

@@ -13,6 +13,17 @@ from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
 DEV = "cuda"
 
 
+@pytest.fixture(params=["f16x3", "f32"], autouse=True)
+def gemm_mode(request):
+    """Every test runs with the Trainer's hidden-block products on both layer-kernel families (split-f16 on the f16
+    matrix cores after a float32 calibration step / float32-input MFMA throughout); same tolerances."""
+    from clavaddpm_amd import split_nets
+    before = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode(request.param)
+    yield request.param
+    split_nets.set_gemm_mode(before)
+
+
 def _setup(K, n_num, state, T=1000):
     d_in = n_num + (sum(K) if K[0] else 0)
     net = MLPDiffusion(d_in, 0, "none", {"d_layers": [64, 64], "dropout": 0.0})
