@@ -117,10 +117,16 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
             ah[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_hi);
             al[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_lo);
         }
+        // W fragments are read one MFMA group ahead: the reads of group i+1 are in flight while group i multiplies
+        h8 wh = *reinterpret_cast<const h8*>(frW + cur + off_hi);
+        h8 wl = *reinterpret_cast<const h8*>(frW + cur + off_lo);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const h8 wh = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_hi);
-            const h8 wl = *reinterpret_cast<const h8*>(frW + cur + i * 2048 + off_lo);
+            h8 wh_n = wh, wl_n = wl;
+            if (i + 1 < TN) {
+                wh_n = *reinterpret_cast<const h8*>(frW + cur + (i + 1) * 2048 + off_hi);
+                wl_n = *reinterpret_cast<const h8*>(frW + cur + (i + 1) * 2048 + off_lo);
+            }
             // the DMA of the stage NS-1 blocks ahead is issued behind the fragment reads of the first half of the wave's
             // MFMA groups: its issue cost (~100 cycles per instruction) hides under MFMAs
             if (more) {
@@ -134,6 +140,7 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[j], acc[i][j], 0, 0, 0);
             }
+            wh = wh_n; wl = wl_n;
         }
         // stage kb+1 must have landed (this wave's part) and every wave must be done reading stage kb before the next
         // iteration overwrites it; in the tail (nothing issued this iteration) the queue is simply drained
