@@ -60,3 +60,15 @@ def test_hip_gaussian_mixture_fit_predict_matches_sklearn():
     assert got.n_iter_ == ref.n_iter_
     np.testing.assert_allclose(got.means_, ref.means_, rtol=1e-8, atol=1e-10)
     assert np.array_equal(got.predict(X), ref.predict(X))
+
+
+def test_row_sharded_estep_equals_the_single_call():
+    from clavaddpm_amd import parallel
+    rng = np.random.RandomState(3)
+    N, d, k = 5001, 20, 7
+    X, means, pc, w = rng.standard_normal((N, d)), rng.standard_normal((k, d)), rng.uniform(0.5, 2.0, (k, d)), rng.dirichlet(np.ones(k))
+    f = lambda a: torch.from_numpy(a).to(DEV)
+    lpn, _, lab = gmm_estep(f(X), f(w), f(means), f(pc), want_resp=False)
+    parts = [parallel.gmm_estep_rows(X, w, means, pc, rank=r, world=3, gather=False) for r in range(3)]
+    assert torch.equal(torch.cat([p[1] for p in parts]), lab.cpu().long())
+    assert torch.equal(torch.cat([p[0] for p in parts]), lpn.cpu())        # rows are independent: bit-identical

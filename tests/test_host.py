@@ -145,3 +145,19 @@ def test_gather_and_gradient_average_world_size_2_gloo():
         assert rows == [float(i) for i in range(11)]           # rank order, ragged slices (6 + 5)
         assert eshape == (2, 3)                                # a rank with zero rows still takes part
         assert g == [1.5] * 5                                  # mean of (1, 2)
+
+
+def test_relations_are_assigned_to_ranks_deterministically():
+    """configs/berka.json: 8 tables, per-relation denoisers trained on separate GPUs (no collective)."""
+    rel = [(None, "district"), ("district", "account"), ("district", "client"), ("account", "loan"), ("account", "order"),
+           ("account", "trans"), ("account", "disp"), ("disp", "card")]
+    cost = {r: c for r, c in zip(rel, [77, 4500, 5369, 682, 6471, 1056320, 5369, 892])}
+    plan = parallel.assign_relations(rel, 8, cost)
+    key = lambda r: (str(r[0]), r[1])
+    assert sorted(sum(plan.values(), []), key=key) == sorted(rel, key=key) and all(len(v) == 1 for v in plan.values())
+    plan3 = parallel.assign_relations(rel, 3, cost)
+    assert sorted(sum(plan3.values(), []), key=key) == sorted(rel, key=key)
+    assert plan3[0] == [("account", "trans")]                      # the 1 M-row table gets a GPU to itself
+    assert plan3 == parallel.assign_relations(list(rel), 3, dict(cost))
+    one = parallel.assign_relations(rel, 1)
+    assert one == {0: rel}                                         # original order kept inside a rank
