@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--clusters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=40)
-    ap.add_argument("--train-steps", type=int, default=100, help="timed training steps for the secondary metric (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=400, help="timed training steps for the secondary metric (0 = skip)")
     ap.add_argument("--no-gmm", action="store_true", help="skip the GMM E-step leg")
     ap.add_argument("--fit-steps", type=int, default=600, help="Trainer steps that fit the denoiser to the synthetic table before sampling")
     ap.add_argument("--gemm", choices=["f16x3", "f32"], default="f16x3",

@@ -41,6 +41,8 @@ class Trainer:
         self.eps = 1e-8
         self.ema_rate = 0.999
         self.opt_step = 0
+        import os
+        self._use_graph = os.environ.get("CLAVA_TRAIN_GRAPH", "1") != "0"
 
         net = diffusion._denoise_fn
         self.layout = _tr.FlatLayout(net)
@@ -107,9 +109,13 @@ class Trainer:
                 v.copy_(p.data)
                 p.data = v
         x = x.to(self.device)
+        st = self._split_state()
+        if (st is not None and not st.due() and draws is None and not d.has_cat and self._use_graph):
+            done = self._graphed_split_step(x, st)
+            if done is not None:
+                return self._optimizer_step(x, done[0], done[1])
         t, noise, u, seed = _tr.draw(d, x, draws)
         x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
-        st = self._split_state()
         if st is None or st.due():
             # float32 step (always when CLAVA_GEMM=f32; every `period`-th step otherwise, to re-fix the plane scales)
             model_out, saved = _tr.denoiser_forward(net, x_in, t)
@@ -122,6 +128,37 @@ class Trainer:
             model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
             loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
             _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
+        return self._optimizer_step(x, loss_multi, loss_gauss)
+
+    def _graphed_split_step(self, x, st):
+        """The split-f16 step (draws, q-sample, forward, losses, backward into the gradient slabs) as ONE hipGraph launch.
+        The step is ~100 small host calls; at 1.0 ms of GPU work per step the Python side is the bottleneck otherwise.
+        The graph is re-captured whenever the plane scales change (every calibration) or the batch shape does; the
+        first split step after a calibration runs eagerly and allocates the buffers the capture then reuses.  Not used
+        with injected draws, categorical columns (their Philox seed is a by-value kernel argument) or CLAVA_TRAIN_GRAPH=0."""
+        key = (tuple(x.shape), st.generation)
+        gr = getattr(self, "_graph", None)
+        if gr is None or gr["key"] != key:
+            if getattr(self, "_graph_warm", None) != key:
+                self._graph_warm = key
+                return None
+            d = self.diffusion
+            net = d._denoise_fn
+            static_x = x.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                t, noise, u, seed = _tr.draw(d, static_x, None)
+                x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed)
+                model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
+                lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+                _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
+            gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise)}
+        gr["x"].copy_(x)
+        gr["graph"].replay()
+        st.steps_since += 1
+        return gr["lm"], gr["lg"]
+
+    def _optimizer_step(self, x, loss_multi, loss_gauss):
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)

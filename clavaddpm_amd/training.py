@@ -128,15 +128,21 @@ class SplitTrainState:
     (weights), i.e. a factor 1000 / 64 below the float16 limit, far more than anything moves in `period` steps at
     training learning rates.  The device overflow flag is read at the same cadence; a raised flag is an error."""
 
-    def __init__(self, period=50):
+    def __init__(self, period=200):
         self.period = period
         self.shift_h = self.shift_g = self.shift_w = None
         self.flag = None
         self.steps_since = None
+        self.generation = 0       # bumped by every calibration: captured graphs bake the scales in
         self.bufs = {}
 
     def due(self):
         return self.shift_h is None or self.steps_since >= self.period
+
+    def side_stream(self, device):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def buf(self, key, rows, cols, device):
         b = self.bufs.get(key)
@@ -161,6 +167,7 @@ class SplitTrainState:
         self.shift_h = [shift_for(x, TARGET_LOG2) for x in v[n:2 * n]]
         self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:]]
         self.steps_since = 0
+        self.generation += 1
 
 
 def denoiser_forward_split(net, x_in, t, st):
@@ -216,12 +223,27 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     names = ["proj"] + [f"mlp.blocks.{i}.linear" for i in range(n_blocks)] + ["mlp.head"]
     ws, _, _ = net.stack()
     n = len(ws)
+    # Weight / bias gradients only consume (g_l, h_{l-1}); nothing in the input-gradient chain waits for them.  They run
+    # on a second stream beside that chain (float32 MFMA wgrad kernels filling the split-f16 kernels' bubbles) and are
+    # joined before the optimizer.  Tensors handed to the side stream are kept alive until the next step.
+    main = torch.cuda.current_stream()
+    side = st.side_stream(dev)
+    keep = []
+
+    def param_grads_async(prefix, dy, inp):
+        ev = torch.cuda.Event()
+        ev.record(main)
+        keep.append((dy, inp))
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            param_grads(prefix, dy, inp)
+
     # head (float32): parameter gradients and the gradient w.r.t. the last hidden pre-activation
-    param_grads(names[n - 1], d_out, hs[n - 2])
+    param_grads_async(names[n - 1], d_out, hs[n - 2])
     g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
     gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
     for l in range(n - 2, 0, -1):
-        param_grads(names[l], g, hs[l - 1])
+        param_grads_async(names[l], g, hs[l - 1])
         w = ws[l].detach()
         wt = ops.split_pack_transposed(w, st.shift_w[l], st.flag, out=st.buf(("wt", l), w.shape[1], w.shape[0], dev))
         if l - 1 >= 1:
@@ -229,11 +251,15 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
                                      out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)
         else:                                     # layer 0 = proj has no activation; only the float32 gradient is needed
             g = ops.linear_f16x3(gs, wt, out_f32=True, overflow=st.flag)
-    param_grads("proj", g, x_in)
-    param_grads("time_embed.2", g, a1)
+    param_grads_async("proj", g, x_in)
+    param_grads_async("time_embed.2", g, a1)
     d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
     d_z1 = _silu_backward(z1, d_a1)
-    param_grads("time_embed.0", d_z1, te)
+    param_grads_async("time_embed.0", d_z1, te)
+    done = torch.cuda.Event()
+    done.record(side)
+    main.wait_event(done)
+    st.keep = keep            # released by the next step, after the join above is on the main stream's queue
     st.steps_since += 1
     return None
 
