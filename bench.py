@@ -328,6 +328,18 @@ def main():
         f32_leg = {"rows_per_s_per_gpu": round(B / dt32, 1), "ms_per_chain": round(1e3 * dt32, 1),
                    "max_rel_dev_of_f16x3_samples": dev_rel}
 
+    # the same chain through the public drop-in API (`conditional_sample`: label upload, chain, float64 result copied to
+    # the host as the reference returns it) - the PCIe-inclusive rate; never `value`
+    api = None
+    if rank == 0:
+        ys_cpu = ys.cpu()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        xs, _ = diff.conditional_sample(ys=ys_cpu, model_kwargs={"y": ys_cpu}, cond_fn=cond_fn, seed=seed + 99, row_offset=0)
+        dt_api = time.perf_counter() - t1
+        api = {"rows_per_s_per_gpu": round(B / dt_api, 1), "ms_per_chain": round(1e3 * dt_api, 1),
+               "note": "diffusion.conditional_sample(...) incl. host<->device copies of labels and samples"}
+
     gmm = None
     if rank == 0 and not args.no_gmm:
         gmm = gmm_bench(device, 1_000_000, 32, 50, 20, 200_000 if not args.no_cpu_baseline else 20_000)
@@ -347,6 +359,7 @@ def main():
         "roofline": roofline,
         "train": train,
         "f32_mfma_path": f32_leg,
+        "api_path_incl_pcie": api,
         "gmm_estep": gmm,
         "sample_absmax": round(x_absmax, 3),
         "f16x3_fallbacks": split_nets.fallback_count,
