@@ -1,0 +1,360 @@
+"""Training of the cluster-guidance classifier on the HIP library.
+
+Mirrors the loop of `train_classifier` (`pipeline_utils.py:783-817`) around `numerical_forward_backward_log`
+(`:655-700`) for the reference `Classifier` in train mode (`:584-630`):
+
+    t ~ uniform{0..T-1};  x_t = gaussian_q_sample(x, t)                                     (:676-677)
+    logits = classifier(x_t, t)     Linear -> ReLU/LeakyReLU -> BatchNorm1d(batch stats) -> Dropout(0.5) blocks
+    loss = cross_entropy(logits, labels, 'none');  acc@1, acc@5                             (:683-693)
+    loss.mean().backward(loss.mean())       <- the reference back-propagates the mean loss scaled by ITSELF (:696-700)
+    AdamW(lr, weight_decay=0.01).step()                                                     (:766, :801)
+
+One step = q-sample kernel -> GEMMs with fused bias/activation -> BatchNorm+Dropout kernels -> cross-entropy kernels
+-> backward (BatchNorm/Dropout/activation in two kernels per block, input / weight / bias gradients on the GEMM and
+column-sum kernels, all writing gradient slabs) -> ONE fused AdamW kernel over a flat parameter buffer.  Nothing is read
+back to the host inside a step: the mean loss stays on the device (also as the gradient scale), Dropout masks come from
+the counter-based generator keyed by a device-resident step counter, so the whole step replays as one hipGraph.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from . import training as _tr
+from ._lib import ACT_LEAKY, ACT_RELU, c_float, c_int, check, lib, ptr, stream_ptr
+from .tab_ddpm.modules import timestep_embedding
+
+c_ll = ctypes.c_longlong
+c_u64 = ctypes.c_ulonglong
+c_u32 = ctypes.c_uint
+BN_MOMENTUM = 0.1
+
+
+def _blocks(clf):
+    """[(linear, act code, slope, batchnorm, dropout p)] of the hidden blocks and the output Linear of `clf.model`."""
+    mods = list(clf.model)
+    out, j = [], 0
+    while j + 3 < len(mods):
+        lin, act, bn, dr = mods[j:j + 4]
+        relu = isinstance(act, nn.ReLU)
+        out.append((j, lin, ACT_RELU if relu else ACT_LEAKY, 0.0 if relu else float(getattr(act, "negative_slope", 0.01)), bn,
+                    float(dr.p)))
+        j += 4
+    return out, j, mods[j]
+
+
+def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=True):
+    B, C = a.shape
+    dev = a.device
+    mean = torch.empty(C, device=dev, dtype=torch.float32)
+    invstd = torch.empty(C, device=dev, dtype=torch.float32)
+    h = torch.empty((B, C), device=dev, dtype=torch.float32)
+    check(lib().clava_bn_dropout_train_f32(ptr(a), c_int(a.stride(0)), c_int(B), c_int(C), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                           ptr(bn.running_mean) if update_running else None,
+                                           ptr(bn.running_var) if update_running else None, c_float(BN_MOMENTUM if bn.momentum is None else bn.momentum),
+                                           c_float(bn.eps), c_float(p), ptr(keep), c_int(keep.stride(0) if keep is not None else 0),
+                                           c_u64(seed), c_u32(step), ptr(step_dev), c_u32(layer), ptr(ws), ptr(mean), ptr(invstd),
+                                           ptr(h), c_int(h.stride(0)), stream_ptr()), "clava_bn_dropout_train_f32")
+    if update_running:
+        bn.num_batches_tracked += 1
+    return h, mean, invstd
+
+
+def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=None):
+    """Train-mode `Classifier.forward` keeping what the backward needs.  `keeps`: per-block uint8 [B, C_i] Dropout keep
+    masks (parity tests) or None for the in-kernel generator keyed by (seed, step or *step_dev, block)."""
+    te = timestep_embedding(t, clf.dim_t)
+    w0, b0 = clf.time_embed[0].weight.detach(), clf.time_embed[0].bias.detach()
+    w2, b2 = clf.time_embed[2].weight.detach(), clf.time_embed[2].bias.detach()
+    z1 = ops.linear(te, w0, b0)
+    a1 = _tr._silu(z1)
+    emb = ops.linear(a1, w2, b2)
+    h = ops.linear(x_t, clf.proj.weight.detach(), clf.proj.bias.detach(), rowadd=emb)
+    blocks, _, head = _blocks(clf)
+    need = lib().clava_bn_workspace_floats
+    need.restype = ctypes.c_longlong
+    ws = torch.empty(int(need(c_int(max(b[1].out_features for b in blocks)))), device=x_t.device, dtype=torch.float32)
+    hs, acts, stats = [h], [], []
+    for i, (j, lin, act, slope, bn, p) in enumerate(blocks):
+        a = ops.linear(hs[-1], lin.weight.detach(), lin.bias.detach(), act="relu" if act == ACT_RELU else "leaky_relu")
+        keep = keeps[i] if keeps is not None else None
+        h, mean, invstd = _bn_dropout(a, bn, p, keep, seed, step, step_dev, i, ws)
+        acts.append(a)
+        stats.append((mean, invstd))
+        hs.append(h)
+    logits = ops.linear(hs[-1], head.weight.detach(), head.bias.detach())
+    return logits, (x_t, te, z1, a1, hs, acts, stats)
+
+
+def cross_entropy(logits, labels, want_acc=True):
+    """Per-row loss, logsumexp, acc@1 and acc@5 indicators (acc@5 only when there are >= 5 classes, `:690`)."""
+    B, C = logits.shape
+    dev = logits.device
+    rows = torch.empty(B, device=dev, dtype=torch.float32)
+    lse = torch.empty(B, device=dev, dtype=torch.float32)
+    acc1 = torch.empty(B, device=dev, dtype=torch.float32) if want_acc else None
+    acc5 = torch.empty(B, device=dev, dtype=torch.float32) if want_acc and C >= 5 else None
+    check(lib().clava_cross_entropy_rows_f32(ptr(logits), c_int(logits.stride(0)), ptr(labels), c_int(B), c_int(C), ptr(rows),
+                                             ptr(acc1), ptr(acc5), ptr(lse), stream_ptr()), "clava_cross_entropy_rows_f32")
+    return rows, lse, acc1, acc5
+
+
+def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, keeps=None, seed=0, step=0, step_dev=None,
+                        splits=_tr.GRAD_SPLITS):
+    """Fills `slabs` [splits, layout.total] with the partial gradients of every live parameter for the upstream gradient
+    `scale[0] / B` on each row's cross-entropy (`scale`: 0-dim device tensor, the batch-mean loss in the reference)."""
+    x_t, te, z1, a1, hs, acts, stats = saved
+    B, C = logits.shape
+    dev = logits.device
+    total = layout.total
+    dl = torch.empty((B, C), device=dev, dtype=torch.float32)
+    check(lib().clava_cross_entropy_grad_f32(ptr(logits), c_int(logits.stride(0)), ptr(labels), ptr(lse), c_int(B), c_int(C), ptr(scale),
+                                             c_float(1.0 / B), ptr(dl), c_int(dl.stride(0)), stream_ptr()), "clava_cross_entropy_grad_f32")
+
+    def param_grads(prefix, dy, inp):
+        wi = layout.index[prefix + ".weight"]
+        ops.linear_wgrad(dy, inp, splits=splits, out=slabs[:, layout.offsets[wi]:], slab_stride=total)
+        bi = layout.index[prefix + ".bias"]
+        check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(dy.shape[0]), c_int(dy.shape[1]), c_int(splits),
+                                           ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
+
+    blocks, jl, head = _blocks(clf)
+    param_grads(f"model.{jl}", dl, hs[-1])
+    dh = ops.linear_dgrad(dl, head.weight.detach())
+    for i in range(len(blocks) - 1, -1, -1):
+        j, lin, act, slope, bn, p = blocks[i]
+        a = acts[i]
+        mean, invstd = stats[i]
+        keep = keeps[i] if keeps is not None else None
+        dz = torch.empty_like(a)
+        gi, bi = layout.index[f"model.{j + 2}.weight"], layout.index[f"model.{j + 2}.bias"]
+        check(lib().clava_bn_dropout_backward_f32(ptr(dh), c_int(dh.stride(0)), ptr(a), c_int(a.stride(0)), c_int(B), c_int(a.shape[1]),
+                                                  ptr(mean), ptr(invstd), ptr(bn.weight.detach()), c_float(p), ptr(keep),
+                                                  c_int(keep.stride(0) if keep is not None else 0), c_u64(seed), c_u32(step), ptr(step_dev),
+                                                  c_u32(i), c_int(act), c_float(slope), c_int(splits), ptr(slabs[:, layout.offsets[gi]:]),
+                                                  ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), ptr(dz), c_int(dz.stride(0)),
+                                                  stream_ptr()), "clava_bn_dropout_backward_f32")
+        param_grads(f"model.{j}", dz, hs[i])
+        dh = ops.linear_dgrad(dz, lin.weight.detach())
+    g = dh                                             # gradient w.r.t. proj(x) + emb
+    param_grads("proj", g, x_t)
+    param_grads("time_embed.2", g, a1)
+    d_a1 = ops.linear_dgrad(g, clf.time_embed[2].weight.detach())
+    d_z1 = _tr._silu_backward(z1, d_a1)
+    param_grads("time_embed.0", d_z1, te)
+
+
+class ClassifierTrainer:
+    """The training loop of `train_classifier` (`pipeline_utils.py:759-817`) for an already constructed `Classifier`
+    and a schedule-only `GaussianMultinomialDiffusion` (`denoise_fn=None`, `:768-777`).
+
+    `run_loop(train_iter, steps, val_iter=None)` consumes `(x float[B, >= n_num], labels long[B])` batches like the
+    reference's data loaders; `history` collects (step, train loss, acc@1, acc@5[, val loss, val acc@1]) rows every
+    `log_interval` steps (the reference's logger means, `:816-817`) without synchronising in between."""
+
+    def __init__(self, classifier, diffusion, lr=0.0001, weight_decay=0.01, device=None, remove_first_col=False):
+        self.classifier = classifier
+        self.diffusion = diffusion
+        self.lr, self.weight_decay = lr, weight_decay
+        self.betas, self.eps = (0.9, 0.999), 1e-8
+        self.remove_first_col = remove_first_col
+        self.eval_interval, self.log_interval = 5, 10
+        dev = next(classifier.parameters()).device if device is None else torch.device(device)
+        _lib.require_cuda(next(classifier.parameters()))
+        self.device = dev
+        # the reference hands classifier.parameters() to AdamW, including the never-called nn.Transformer (`:591-595`);
+        # its gradients stay None, so torch skips it: only the live parameters are optimised here
+        self.layout = _tr.FlatLayout(classifier, skip_prefixes=("transformer_layer",))
+        total = self.layout.total
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._flattened = False
+        self._flatten()
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.slabs = torch.zeros((_tr.GRAD_SPLITS, total), device=dev, dtype=torch.float32)
+        self.opt_step = 0
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)      # Dropout step counter, advanced on the device
+        self.history = []
+        self._use_graph = os.environ.get("CLAVA_TRAIN_GRAPH", "1") != "0"
+        self._graph = None
+        self.world = 1
+        self.dist = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self.dist = torch.distributed
+            self.world = self.dist.get_world_size()
+            self.dist.broadcast(self.flat, src=0)
+            self.grad_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+
+    def _flatten(self):
+        if self._flattened:
+            return
+        live = dict(self.classifier.named_parameters())
+        for name in self.layout.names:
+            v = self.layout.view(self.flat, name)
+            v.copy_(live[name].data)
+            live[name].data = v
+        self._flattened = True
+
+    def finalize(self):
+        """Give every parameter its own storage again (the classifier is pickled with the run, complex_pipeline.py:64)."""
+        if self._flattened:
+            live = dict(self.classifier.named_parameters())
+            for name in self.layout.names:
+                live[name].data = live[name].data.clone()
+            self._flattened = False
+
+    def load_adam_state(self, exp_avg, exp_avg_sq, steps_done):
+        """Resume from recorded Adam moments ({parameter name: tensor}) after `steps_done` optimizer steps."""
+        for name in self.layout.names:
+            self.layout.view(self.exp_avg, name).copy_(exp_avg[name].to(self.device))
+            self.layout.view(self.exp_avg_sq, name).copy_(exp_avg_sq[name].to(self.device))
+        self.opt_step = int(steps_done)
+
+    # ------------------------------------------------------------------------------------------------ one step
+    def _inputs(self, x, labels, draws):
+        d = self.diffusion
+        n = d.num_numerical_features
+        dev = self.device
+        x = x.to(dev)
+        if self.remove_first_col:
+            x = x[:, 1:]
+        x_num = x[:, :n].float().contiguous()
+        labels = labels.to(dev).long().contiguous()
+        return x_num, labels
+
+    def _noised(self, x_num, draws):
+        d = self.diffusion
+        B, n = x_num.shape
+        dev = x_num.device
+        if draws is not None:
+            t = draws["t"].to(dev).long().contiguous()
+            noise = draws["noise"].to(dev).float().contiguous()
+        else:
+            t = torch.randint(0, d.num_timesteps, (B,), device=dev).long()      # UniformSampler.sample (:676)
+            noise = torch.randn((B, n), device=dev, dtype=torch.float32)
+        x_t = torch.empty((B, n), device=dev, dtype=torch.float32)
+        sched = d._c_schedule()
+        check(lib().clava_gauss_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(x_num), ptr(noise), ptr(t), ptr(x_t), c_int(n),
+                                            stream_ptr()), "clava_gauss_qsample_f32")
+        return x_t, t
+
+    def _forward_backward(self, x_num, labels, draws):
+        clf = self.classifier
+        keeps = None
+        if draws is not None and draws.get("keep") is not None:
+            keeps, off = [], 0
+            k = draws["keep"].to(self.device).to(torch.uint8)
+            for b in _blocks(clf)[0]:
+                C = b[1].out_features
+                keeps.append(k[:, off:off + C].contiguous())
+                off += C
+        x_t, t = self._noised(x_num, draws)
+        B = x_t.shape[0]
+        logits, saved = classifier_forward_train(clf, x_t, t, keeps, self.seed, 0, self.step_dev)
+        rows, lse, acc1, acc5 = cross_entropy(logits, labels)
+        loss = _tr._device_sum(rows, 1.0 / B)
+        a1 = _tr._device_sum(acc1, 1.0 / B)
+        a5 = _tr._device_sum(acc5, 1.0 / B) if acc5 is not None else None
+        classifier_backward(clf, saved, logits, labels, lse, loss, self.layout, self.slabs, keeps, self.seed, 0, self.step_dev)
+        self.step_dev += 1
+        return loss, a1, a5, (saved, logits, rows, lse, acc1, acc5, x_t, t)
+
+    def _graphed(self, x_num, labels):
+        key = (tuple(x_num.shape),)
+        gr = self._graph
+        if gr is None or gr["key"] != key:
+            if getattr(self, "_graph_warm", None) != key:          # first step of a shape runs eagerly (allocator warm-up)
+                self._graph_warm = key
+                return None
+            sx, sy = x_num.clone(), labels.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_backward(sx, sy, None)
+            gr = self._graph = {"key": key, "graph": graph, "x": sx, "y": sy, "out": out}
+        gr["x"].copy_(x_num)
+        gr["y"].copy_(labels)
+        gr["graph"].replay()
+        return gr["out"][:3]
+
+    def step(self, x, labels, draws=None):
+        """One training iteration (`:791-801`).  Returns device scalars (mean loss, acc@1, acc@5 or None)."""
+        if not self.classifier.training:
+            raise _lib.ClavaHipError("ClassifierTrainer.step needs classifier.train()")
+        if not self._flattened:
+            self._flatten()
+        x_num, labels = self._inputs(x, labels, draws)
+        out = None
+        if draws is None and self._use_graph and self.dist is None:
+            out = self._graphed(x_num, labels)
+        if out is None:
+            out = self._forward_backward(x_num, labels, draws)[:3]
+        self.opt_step += 1
+        if self.dist is not None:
+            _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
+            self.dist.all_reduce(self.grad_flat)
+            g, S = self.grad_flat, 1
+        else:
+            g, S = self.slabs, _tr.GRAD_SPLITS
+        check(lib().clava_adamw_ema_f32(ptr(self.flat), None, ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(g), c_int(S),
+                                        c_ll(self.layout.total), c_float(1.0), c_ll(self.layout.total), ctypes.c_double(self.lr),
+                                        ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
+                                        ctypes.c_double(self.weight_decay), c_ll(self.opt_step), ctypes.c_double(0.0), stream_ptr()),
+              "clava_adamw_ema_f32")
+        return out
+
+    def gradients(self):
+        """{name: gradient} of the last step (sum of the slabs), for tests."""
+        flat = _tr.reduce_slabs(self.slabs)
+        return {n: self.layout.view(flat, n).clone() for n in self.layout.names}
+
+    def evaluate(self, x, labels, draws=None):
+        """The `prefix='val'` call (`:803-814`): eval-mode forward on a noised batch; (mean loss, acc@1, acc@5 or None)."""
+        clf = self.classifier
+        was = clf.training
+        clf.eval()
+        try:
+            x_num, labels = self._inputs(x, labels, draws)
+            x_t, t = self._noised(x_num, draws)
+            logits = clf(x_t, t)
+            rows, _, acc1, acc5 = cross_entropy(logits, labels)
+            B = x_t.shape[0]
+            return (_tr._device_sum(rows, 1.0 / B), _tr._device_sum(acc1, 1.0 / B),
+                    _tr._device_sum(acc5, 1.0 / B) if acc5 is not None else None)
+        finally:
+            clf.train(was)
+
+    def run_loop(self, train_iter, steps, val_iter=None):
+        """`for step in range(classifier_steps)` of `:785-817`; leaves the classifier in eval mode like `:820`."""
+        self.classifier.train()
+        dev = self.device
+        sums = torch.zeros(3, device=dev, dtype=torch.float64)
+        vsums = torch.zeros(2, device=dev, dtype=torch.float64)
+        n = nv = 0
+        for step in range(steps):
+            x, y = next(train_iter)
+            loss, a1, a5 = self.step(x, y)
+            sums[0] += loss.double()
+            sums[1] += a1.double()
+            if a5 is not None:
+                sums[2] += a5.double()
+            n += 1
+            if val_iter is not None and not step % self.eval_interval:
+                vx, vy = next(val_iter)
+                vl, va, _ = self.evaluate(vx, vy)
+                vsums[0] += vl.double()
+                vsums[1] += va.double()
+                nv += 1
+            if not step % self.log_interval:                       # logger.dumpkvs(): means since the last dump
+                row = [step] + (sums / n).tolist()
+                if nv:
+                    row += (vsums / nv).tolist()
+                self.history.append(row)
+                sums.zero_()
+                vsums.zero_()
+                n = nv = 0
+        self.finalize()
+        self.classifier.eval()
+        return self.classifier

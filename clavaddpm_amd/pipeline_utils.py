@@ -65,8 +65,9 @@ class Classifier(nn.Module):
     def forward(self, x, timesteps):
         require_cuda(x, timesteps)
         if self.training:
-            raise NotImplementedError("the HIP classifier runs in eval mode (guidance); classifier training is "
-                                      "listed under 'next' in DESIGN.md")
+            raise NotImplementedError("Classifier.forward runs in eval mode (guidance); train it with "
+                                      "clavaddpm_amd.classifier_training.ClassifierTrainer, which runs the train-mode "
+                                      "forward, the backward and AdamW on the HIP library")
         emb = time_embed_forward(self.time_embed, timesteps, self.dim_t)
         ws, bs, acts, sc, sh = self.stack()
         return run_stack(ws, bs, acts, x.float(), rowadd0=emb, bn_scale=sc, bn_shift=sh)[-1]

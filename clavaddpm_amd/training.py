@@ -30,10 +30,12 @@ def param_list(net):
 class FlatLayout:
     """Offsets of every parameter of a denoiser inside one flat float32 buffer."""
 
-    def __init__(self, net):
+    def __init__(self, net, skip_prefixes=()):
         self.names, self.shapes, self.offsets = [], [], []
         off = 0
         for name, p in net.named_parameters():
+            if name.startswith(tuple(skip_prefixes)) if skip_prefixes else False:
+                continue
             self.names.append(name)
             self.shapes.append(tuple(p.shape))
             self.offsets.append(off)

@@ -301,6 +301,44 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
                         long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
                         double eps, double weight_decay, long long step, double ema_rate, void* stream);
 
+/* ---- guidance-classifier training (train_classifier / numerical_forward_backward_log) --------
+ * One hidden block of Classifier (pipeline_utils.py:607-617) in train mode is Linear -> ReLU/LeakyReLU -> BatchNorm1d
+ * -> Dropout.  The Linear + activation is clava_gemm_bias_act_f32; these entry points are the rest.
+ *
+ * clava_bn_dropout_train_f32: h = dropout(BatchNorm_train(a)) for a[B,C] (the activation output).  Batch mean and
+ * biased variance per channel (nn.BatchNorm1d in training mode, eps inside the square root), running statistics
+ * updated in place with `momentum` and the unbiased variance (pass NULL for both to skip), save_mean / save_invstd [C]
+ * kept for the backward.  Dropout keeps an element with probability 1-p and scales kept ones by 1/(1-p) (nn.Dropout);
+ * the keep decision comes from keep_mask[B,C] bytes (parity tests) or, when NULL, from the counter-based generator
+ * keyed by (seed, step, layer < 32, row, column); when step_dev != NULL the step index is read from that DEVICE word
+ * instead, so that a captured graph can advance it.  workspace holds clava_bn_workspace_floats(C) floats. */
+long long clava_bn_workspace_floats(int C);
+int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, float p, const unsigned char* keep_mask,
+                               int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
+                               float* workspace,
+                               float* save_mean, float* save_invstd, float* h, int ldh, void* stream);
+/* Backward of the block above, from dh (gradient w.r.t. the dropout output) to dz (gradient w.r.t. the Linear output):
+ * dy = dh * keep/(1-p); dbeta = sum_b dy, dgamma = sum_b dy*xhat, written as `splits` partial sums over batch ranges at
+ * dbeta_slabs / dgamma_slabs + s*slab_stride (the layout clava_adamw_ema_f32 sums); dz = act'(a) * gamma*invstd *
+ * (dy - dbeta/B - xhat*dgamma/B) with act'(a) = a > 0 ? 1 : slope (act = CLAVA_ACT_NONE: no activation factor).
+ * Replaces autograd's backward through model.{j+1..j+3} of the reference Classifier. */
+int clava_bn_dropout_backward_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
+                                  const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
+                                  int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
+                                  int act, float slope,
+                                  int splits, float* dgamma_slabs, float* dbeta_slabs, long long slab_stride, float* dz,
+                                  int lddz, void* stream);
+/* F.cross_entropy(logits, labels, reduction='none') per row (pipeline_utils.py:683) with the row's logsumexp and the
+ * acc@1 / acc@5 indicators of compute_top_k (pipeline_utils.py:640-645; either may be NULL). */
+int clava_cross_entropy_rows_f32(const float* logits, int ld, const long long* labels, int B, int C, float* loss_rows, float* acc1,
+                                 float* acc5, float* lse, void* stream);
+/* dlogits = factor * scale[0] * (softmax(logits) - onehot(labels)).  `scale` is a DEVICE scalar or NULL: the reference
+ * back-propagates loss.backward(loss) (pipeline_utils.py:700), i.e. the batch-mean loss multiplies its own gradient;
+ * passing the device-resident mean keeps the step free of host synchronisation. */
+int clava_cross_entropy_grad_f32(const float* logits, int ld, const long long* labels, const float* lse, int B, int C,
+                                 const float* scale, float factor, float* dlogits, int ldd, void* stream);
+
 /* ---- GMM E-step (parent-child clustering) ----------------------------------------------------------------
  * Diagonal-covariance mixture E-step in float64 for X[N,d] (row-major, leading dimension ldx) and k <= 64 components:
  *   log_prob_norm[N], log_resp[N,k] (may be NULL), labels[N] = argmax_c weighted log-probability (may be NULL).

@@ -25,7 +25,8 @@ def timestep_embedding(t, dim, max_period=10000):
 
 def time_mlp(p, prefix, t, dim_t):
     """`time_embed` = Linear -> SiLU -> Linear (`modules.py:445-449`, `pipeline_utils.py:597-601`)."""
-    h = F.linear(timestep_embedding(t, dim_t), p[prefix + "0.weight"], p[prefix + "0.bias"])
+    w0 = p[prefix + "0.weight"]
+    h = F.linear(timestep_embedding(t, dim_t).to(w0.dtype), w0, p[prefix + "0.bias"])   # (float64 copies: conditioning checks)
     return F.linear(F.silu(h), p[prefix + "2.weight"], p[prefix + "2.bias"])
 
 

@@ -68,6 +68,14 @@ def ref_cond_fn(classifier, classifier_scale):
     return _compile(node, ns, "pipeline_utils.py")
 
 
+def ref_classifier_train_step(logger):
+    """`numerical_forward_backward_log` and the helpers it calls, compiled from pipeline_utils.py:632-700."""
+    ns = {"torch": torch, "F": F, "logger": logger}
+    for name in ("split_microbatches", "compute_top_k", "log_loss_dict", "numerical_forward_backward_log"):
+        _compile(_extract("pipeline_utils.py", name), ns, "pipeline_utils.py")
+    return ns["numerical_forward_backward_log"]
+
+
 def ref_trainer_cls():
     import pandas as pd
     ns = {"torch": torch, "np": np, "pd": pd, "deepcopy": deepcopy}
@@ -394,9 +402,108 @@ def g9_gmm():
          log_prob_norm=lpn, log_resp=lr, labels=gmm.predict(X).astype(np.int64))
 
 
+# --------------------------------------------------------------------------- G10
+def g10_classifier_training():
+    """The classifier training loop of `train_classifier` (pipeline_utils.py:783-817) on the reference's own
+    `numerical_forward_backward_log`, `Classifier` (train mode), uniform schedule sampler, logger and torch AdamW;
+    every draw (timesteps from np.random.choice, q-sample noise, Dropout keep masks) is recorded."""
+    import tempfile
+    import types
+    from tab_ddpm import logger
+    from tab_ddpm.resample import create_named_schedule_sampler
+    logger.configure(dir=tempfile.mkdtemp(), format_strs=[])
+    fwd_bwd = ref_classifier_train_step(logger)
+    d_in, C, hidden, B, steps, T, lr = 6, 7, [32, 64, 32], 64, 6, 1000, 1e-3
+    g = torch.Generator().manual_seed(10)
+    clf = ref_classifier_cls()(d_in=d_in, d_out=C, dim_t=128, hidden_sizes=hidden)
+    st = load_seeded(clf, classifier_shapes(d_in, C, hidden), seed=101)
+    opt = torch.optim.AdamW(clf.parameters(), lr=lr)                      # :766
+    diffusion = GaussianMultinomialDiffusion(num_classes=np.array([0]), num_numerical_features=d_in, denoise_fn=None,
+                                             gaussian_loss_type="mse", num_timesteps=T, scheduler="cosine",
+                                             device=torch.device("cpu"))       # :768-776
+    sampler = create_named_schedule_sampler("uniform", diffusion)
+    dataset = types.SimpleNamespace(n_num_features=d_in)
+    xs = torch.randn(steps, B, d_in, generator=g)
+    ys = torch.randint(0, C, (steps, B), generator=g)
+    n_val = (steps + 4) // 5
+    vxs = torch.randn(n_val, B, d_in, generator=g)
+    vys = torch.randint(0, C, (n_val, B), generator=g)
+    train_loader = iter([(xs[i].clone(), ys[i].clone()) for i in range(steps)])
+    val_loader = iter([(vxs[i].clone(), vys[i].clone()) for i in range(n_val)])
+
+    masks, ts = [], []
+    drops = [m for m in clf.model if isinstance(m, nn.Dropout)]
+
+    def hook(mod, inp, out):
+        if mod.training:
+            assert not bool((inp[0] == 0).any())
+            masks.append((out != 0).to(torch.uint8))
+    for m in drops:
+        m.register_forward_hook(hook)
+    orig_choice = np.random.choice
+
+    def choice(*a, **k):
+        r = orig_choice(*a, **k)
+        ts.append(torch.from_numpy(np.asarray(r)).long())
+        return r
+    np.random.choice = choice
+    np.random.seed(1010)
+    torch.manual_seed(1011)
+    logs, grads = [], {}
+    live = [k for k, _ in clf.named_parameters() if not k.startswith("transformer_layer")]
+    try:
+        with Tape() as tape:
+            clf.train()                                                      # :783
+            for step in range(steps):                                        # :785-817
+                if step == steps - 1:       # full state in front of the last step: lets a test check that step alone
+                    pd_ = dict(clf.named_parameters())
+                    snap = {"ps:" + k: v.detach().clone() for k, v in clf.state_dict().items()
+                            if not k.startswith("transformer_layer")}
+                    snap.update({"ms:" + k: opt.state[pd_[k]]["exp_avg"].clone() for k in live})
+                    snap.update({"vs:" + k: opt.state[pd_[k]]["exp_avg_sq"].clone() for k in live})
+                fwd_bwd(clf, opt, train_loader, dataset, sampler, diffusion, prefix="train", device="cpu")
+                if step in (0, steps - 1):
+                    pd_ = dict(clf.named_parameters())
+                    grads[step] = {k: pd_[k].grad.detach().clone() for k in live}
+                opt.step()
+                if not step % 5:
+                    with torch.no_grad():
+                        clf.eval()
+                        fwd_bwd(clf, opt, val_loader, dataset, sampler, diffusion, prefix="val", device="cpu")
+                        clf.train()
+                logs.append(dict(logger.getkvs()))
+                logger.dumpkvs()
+    finally:
+        np.random.choice = orig_choice
+    noise = [tape.take("randn_like") for _ in range(steps + n_val)]
+    assert not tape.log and len(ts) == steps + n_val and len(masks) == steps * len(drops)
+    is_val = []
+    for step in range(steps):
+        is_val.append(0)
+        if not step % 5:
+            is_val.append(1)
+    tr = [i for i, v in enumerate(is_val) if not v]
+    va = [i for i, v in enumerate(is_val) if v]
+    out = {"d_in": d_in, "C": C, "hidden": np.array(hidden), "T": T, "lr": lr, "steps": steps,
+           "x": xs, "y": ys, "val_x": vxs, "val_y": vys,
+           "t": torch.stack([ts[i] for i in tr]), "noise": torch.stack([noise[i] for i in tr]),
+           "val_t": torch.stack([ts[i] for i in va]), "val_noise": torch.stack([noise[i] for i in va]),
+           "keep": torch.stack([torch.cat(masks[s * len(drops):(s + 1) * len(drops)], dim=1) for s in range(steps)]),
+           "train_loss": np.array([l["train_loss"] for l in logs]), "train_acc1": np.array([l["train_acc@1"] for l in logs]),
+           "train_acc5": np.array([l["train_acc@5"] for l in logs]),
+           "val_loss": np.array([l["val_loss"] for l in logs if "val_loss" in l]),
+           "val_acc1": np.array([l["val_acc@1"] for l in logs if "val_acc@1" in l])}
+    out.update({"p0:" + k: v for k, v in st.items()})
+    out.update(snap)
+    out.update({"p1:" + k: v.detach() for k, v in clf.state_dict().items() if not k.startswith("transformer_layer")})
+    for s_, gd in grads.items():
+        out.update({f"g{s_}:" + k: v for k, v in gd.items()})
+    save("g10_classifier_training.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = {"g1": g1_schedule, "g2": g2_mlp, "g3": g3_gauss_step, "g4": g4_multinomial_step, "g5": g5_chains,
-           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm}
+           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training}
     for w in which:
         fns[w]()

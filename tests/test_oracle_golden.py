@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 import oracle
-from oracle import chain, gaussian, gmm, guidance, loss, multinomial as mn, network, schedule, trainer
+from oracle import chain, classifier_train, gaussian, gmm, guidance, loss, multinomial as mn, network, schedule, trainer
 from conftest import golden, relerr, sub
 
 SCHED_KEYS = ["alphas", "log_alpha", "log_1_min_alpha", "log_1_min_cumprod_alpha", "log_cumprod_alpha",
@@ -162,6 +162,47 @@ def test_g9_gmm_estep():
     np.testing.assert_allclose(lpn, g["log_prob_norm"].numpy(), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(lr, g["log_resp"].numpy(), rtol=1e-10, atol=1e-10)
     assert np.array_equal(lab, g["labels"].numpy())          # cluster assignments: exact
+
+
+def test_g10_classifier_training_trajectory():
+    """Adam turns a relative gradient error on a small-gradient element into an update error of the same relative size,
+    and the ReLU / BatchNorm stack amplifies that from step to step (a 1e-7 perturbation of one weight matrix moves
+    step-5 gradients by 30 %), so only the first step and the last step - restarted from the reference's recorded
+    state - are checked tightly; the trajectory in between is checked loosely."""
+    g = golden("g10_classifier_training.npz")
+    steps, T, lr = int(g["steps"]), int(g["T"]), float(g["lr"])
+    tb = schedule.tables("cosine", T)
+    seq = lambda k, sl: list(g[k][sl])
+    # whole trajectory from the initial state
+    p = {k: v.clone() for k, v in sub(g, "p0:").items()}
+    hist, grads = classifier_train.run_loop(tb, p, seq("x", slice(None)), seq("y", slice(None)), seq("t", slice(None)),
+                                            seq("noise", slice(None)), seq("keep", slice(None)), lr, grads_at=(0,))
+    assert abs(hist[0][0] - float(g["train_loss"][0])) < 1e-6 * abs(hist[0][0])
+    for k, v in grads[0].items():
+        assert relerr(v, g["g0:" + k]) < 1e-5, k
+    for i, (l, a1, a5) in enumerate(hist):
+        assert abs(l - float(g["train_loss"][i])) < 2e-4 * abs(l), i
+        assert abs(a1 - float(g["train_acc1"][i])) < 1e-6 and abs(a5 - float(g["train_acc5"][i])) < 1e-6
+    # the last step alone, from the recorded parameters, BatchNorm buffers and Adam moments
+    last = slice(steps - 1, steps)
+    p = {k: v.clone() for k, v in sub(g, "ps:").items()}
+    hist, grads = classifier_train.run_loop(tb, p, seq("x", last), seq("y", last), seq("t", last), seq("noise", last),
+                                            seq("keep", last), lr, grads_at=(0,),
+                                            adam_state=(sub(g, "ms:"), sub(g, "vs:"), steps - 1))
+    assert abs(hist[0][0] - float(g["train_loss"][steps - 1])) < 1e-6 * abs(hist[0][0])
+    for k, v in grads[0].items():
+        assert relerr(v, g[f"g{steps - 1}:" + k]) < 1e-5, k
+    for k in p:
+        if k.endswith("num_batches_tracked"):
+            assert int(p[k]) == int(g["p1:" + k])
+        else:
+            assert relerr(p[k].detach(), g["p1:" + k]) < 1e-5, k
+    # the eval-mode ('val') pass of step 0 ran after the first optimizer step
+    p = {k: v.clone() for k, v in sub(g, "p0:").items()}
+    first = slice(0, 1)
+    classifier_train.run_loop(tb, p, seq("x", first), seq("y", first), seq("t", first), seq("noise", first), seq("keep", first), lr)
+    vl, va = classifier_train.evaluate(tb, p, g["val_x"][0], g["val_y"][0], g["val_t"][0], g["val_noise"][0])
+    assert abs(vl - float(g["val_loss"][0])) < 1e-5 * abs(vl) and abs(va - float(g["val_acc1"][0])) < 1e-6
 
 
 def test_oracle_header_says_test_only():
