@@ -134,6 +134,52 @@ def train_bench(device, n_num, T, batch, steps, warmup, barrier):
             "steps_timed": steps, "tflops_per_gpu": round(flops * steps / dt / 1e12, 1)}
 
 
+def classifier_train_bench(device, n_num, n_clusters, T, batch, steps, warmup, cpu_steps):
+    """training steps/s of the guidance classifier (q-sample, train-mode forward with BatchNorm batch
+    statistics and Dropout, cross-entropy, backward, AdamW; batch 4096, configs/*.json classifier shape), with the CPU
+    oracle (torch CPU ops like the reference) timed on a few steps of the same shape."""
+    import numpy as np
+    from clavaddpm_amd.classifier_training import ClassifierTrainer
+    from clavaddpm_amd.pipeline_utils import Classifier
+    from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion
+    torch.manual_seed(0)
+    clf = Classifier(d_in=n_num, d_out=n_clusters, dim_t=128, hidden_sizes=list(CLASSIFIER_LAYERS)).to(device).train()
+    diff = GaussianMultinomialDiffusion(np.array([0]), n_num, None, num_timesteps=T, scheduler="cosine",
+                                        device=torch.device(device)).to(device)
+    tr = ClassifierTrainer(clf, diff, lr=1e-4)
+    x = torch.randn(8 * batch, n_num)
+    y = torch.randint(0, n_clusters, (8 * batch,))
+    for i in range(warmup):
+        tr.step(x[(i % 8) * batch:(i % 8 + 1) * batch], y[(i % 8) * batch:(i % 8 + 1) * batch])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(x[(i % 8) * batch:(i % 8 + 1) * batch], y[(i % 8) * batch:(i % 8 + 1) * batch])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dims = [128] + list(CLASSIFIER_LAYERS)
+    macs = 128 * n_num + 2 * 128 * 128 + sum(a * b for a, b in zip(dims[:-1], dims[1:])) + dims[-1] * n_clusters
+    out = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "batch_per_gpu": batch, "steps_timed": steps,
+           "tflops_per_gpu": round(6.0 * batch * macs * steps / dt / 1e12, 1)}
+    if cpu_steps > 0:
+        from oracle import classifier_train as oc, schedule
+        tb = schedule.tables("cosine", T)
+        p = {k: v.detach().cpu().clone() for k, v in clf.state_dict().items()}
+        g = torch.Generator().manual_seed(1)
+        mk = lambda: (torch.randint(0, T, (batch,), generator=g), torch.randn(batch, n_num, generator=g),
+                      (torch.rand(batch, sum(CLASSIFIER_LAYERS), generator=g) < 0.5).to(torch.uint8))
+        draws = [mk() for _ in range(cpu_steps + 1)]
+        run = lambda d: oc.run_loop(tb, p, [x[:batch]] * len(d), [y[:batch]] * len(d), [a[0] for a in d], [a[1] for a in d],
+                                    [a[2] for a in d], 1e-4)
+        run(draws[:1])
+        t0 = time.perf_counter()
+        run(draws[1:])
+        dc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"steps_per_s": round(cpu_steps / dc, 3), "kind": "port", "cores": torch.get_num_threads(),
+                               "sample": f"{cpu_steps} steps, {dc:.1f} s"}
+    return out
+
+
 def gmm_bench(device, n_rows, d, k, iters, cpu_rows):
     """Secondary measurement: the diagonal-covariance GMM E-step of parent-child clustering on a
     movie_lens-rating-sized child table (1 M rows), float64, X resident in HBM across EM iterations.  At k = 50 the kernel
@@ -187,6 +233,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--train-steps", type=int, default=400, help="timed training steps for the secondary metric (0 = skip)")
     ap.add_argument("--no-gmm", action="store_true", help="skip the GMM E-step leg")
+    ap.add_argument("--clf-train-steps", type=int, default=300, help="timed classifier-training steps (0 = skip)")
     ap.add_argument("--fit-steps", type=int, default=600, help="Trainer steps that fit the denoiser to the synthetic table before sampling")
     ap.add_argument("--gemm", choices=["f16x3", "f32"], default="f16x3",
                     help="layer kernels of the sampling loop: split-f16 on the f16 matrix cores (float32-level accuracy) or float32-input MFMA")
@@ -344,6 +391,11 @@ def main():
     if rank == 0 and not args.no_gmm:
         gmm = gmm_bench(device, 1_000_000, 32, 50, 20, 200_000 if not args.no_cpu_baseline else 20_000)
 
+    clf_train = None
+    if rank == 0 and args.clf_train_steps > 0:
+        clf_train = classifier_train_bench(device, args.n_num, args.clusters, T, 4096, args.clf_train_steps, 10,
+                                           0 if args.no_cpu_baseline else 3)
+
     rows = world * B * args.steps
     value = rows / elapsed
     out = {
@@ -361,6 +413,7 @@ def main():
         "f32_mfma_path": f32_leg,
         "api_path_incl_pcie": api,
         "gmm_estep": gmm,
+        "classifier_train": clf_train,
         "sample_absmax": round(x_absmax, 3),
         "f16x3_fallbacks": split_nets.fallback_count,
     }

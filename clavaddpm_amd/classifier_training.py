@@ -15,6 +15,7 @@ column-sum kernels, all writing gradient slabs) -> ONE fused AdamW kernel over a
 back to the host inside a step: the mean loss stays on the device (also as the gradient scale), Dropout masks come from
 the counter-based generator keyed by a device-resident step counter, so the whole step replays as one hipGraph.
 """
+import contextlib
 import ctypes
 import os
 
@@ -73,9 +74,7 @@ def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=N
     emb = ops.linear(a1, w2, b2)
     h = ops.linear(x_t, clf.proj.weight.detach(), clf.proj.bias.detach(), rowadd=emb)
     blocks, _, head = _blocks(clf)
-    need = lib().clava_bn_workspace_floats
-    need.restype = ctypes.c_longlong
-    ws = torch.empty(int(need(c_int(max(b[1].out_features for b in blocks)))), device=x_t.device, dtype=torch.float32)
+    ws = _bn_workspace(max(b[1].out_features for b in blocks), x_t.device)
     hs, acts, stats = [h], [], []
     for i, (j, lin, act, slope, bn, p) in enumerate(blocks):
         a = ops.linear(hs[-1], lin.weight.detach(), lin.bias.detach(), act="relu" if act == ACT_RELU else "leaky_relu")
@@ -101,8 +100,14 @@ def cross_entropy(logits, labels, want_acc=True):
     return rows, lse, acc1, acc5
 
 
+def _bn_workspace(C, device):
+    need = lib().clava_bn_workspace_floats
+    need.restype = ctypes.c_longlong
+    return torch.empty(int(need(c_int(C))), device=device, dtype=torch.float32)
+
+
 def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, keeps=None, seed=0, step=0, step_dev=None,
-                        splits=_tr.GRAD_SPLITS):
+                        splits=_tr.GRAD_SPLITS, side=None):
     """Fills `slabs` [splits, layout.total] with the partial gradients of every live parameter for the upstream gradient
     `scale[0] / B` on each row's cross-entropy (`scale`: 0-dim device tensor, the batch-mean loss in the reference)."""
     x_t, te, z1, a1, hs, acts, stats = saved
@@ -113,14 +118,27 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
     check(lib().clava_cross_entropy_grad_f32(ptr(logits), c_int(logits.stride(0)), ptr(labels), ptr(lse), c_int(B), c_int(C), ptr(scale),
                                              c_float(1.0 / B), ptr(dl), c_int(dl.stride(0)), stream_ptr()), "clava_cross_entropy_grad_f32")
 
+    # Weight / bias gradients only consume (dz_l, h_{l-1}); nothing in the input-gradient chain waits for them, so they
+    # run on a second stream beside that chain (they are small, latency-bound launches) and are joined at the end.
+    main = torch.cuda.current_stream()
+    keep_alive = []
+
     def param_grads(prefix, dy, inp):
-        wi = layout.index[prefix + ".weight"]
-        ops.linear_wgrad(dy, inp, splits=splits, out=slabs[:, layout.offsets[wi]:], slab_stride=total)
-        bi = layout.index[prefix + ".bias"]
-        check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(dy.shape[0]), c_int(dy.shape[1]), c_int(splits),
-                                           ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            keep_alive.append((dy, inp))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if side is not None:
+                side.wait_event(ev)
+            wi = layout.index[prefix + ".weight"]
+            ops.linear_wgrad(dy, inp, splits=splits, out=slabs[:, layout.offsets[wi]:], slab_stride=total)
+            bi = layout.index[prefix + ".bias"]
+            check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(dy.shape[0]), c_int(dy.shape[1]), c_int(splits),
+                                               ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
 
     blocks, jl, head = _blocks(clf)
+    ws = _bn_workspace(max(b[1].out_features for b in blocks), dev)
     param_grads(f"model.{jl}", dl, hs[-1])
     dh = ops.linear_dgrad(dl, head.weight.detach())
     for i in range(len(blocks) - 1, -1, -1):
@@ -133,7 +151,7 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
         check(lib().clava_bn_dropout_backward_f32(ptr(dh), c_int(dh.stride(0)), ptr(a), c_int(a.stride(0)), c_int(B), c_int(a.shape[1]),
                                                   ptr(mean), ptr(invstd), ptr(bn.weight.detach()), c_float(p), ptr(keep),
                                                   c_int(keep.stride(0) if keep is not None else 0), c_u64(seed), c_u32(step), ptr(step_dev),
-                                                  c_u32(i), c_int(act), c_float(slope), c_int(splits), ptr(slabs[:, layout.offsets[gi]:]),
+                                                  c_u32(i), c_int(act), c_float(slope), ptr(ws), c_int(splits), ptr(slabs[:, layout.offsets[gi]:]),
                                                   ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), ptr(dz), c_int(dz.stride(0)),
                                                   stream_ptr()), "clava_bn_dropout_backward_f32")
         param_grads(f"model.{j}", dz, hs[i])
@@ -144,6 +162,11 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
     d_a1 = ops.linear_dgrad(g, clf.time_embed[2].weight.detach())
     d_z1 = _tr._silu_backward(z1, d_a1)
     param_grads("time_embed.0", d_z1, te)
+    if side is not None:
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
+    return keep_alive          # tensors the side stream reads: the caller keeps them until the next step
 
 
 class ClassifierTrainer:
@@ -180,6 +203,8 @@ class ClassifierTrainer:
         self.history = []
         self._use_graph = os.environ.get("CLAVA_TRAIN_GRAPH", "1") != "0"
         self._graph = None
+        self._side = None
+        self._keep = None
         self.world = 1
         self.dist = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
@@ -258,7 +283,10 @@ class ClassifierTrainer:
         loss = _tr._device_sum(rows, 1.0 / B)
         a1 = _tr._device_sum(acc1, 1.0 / B)
         a5 = _tr._device_sum(acc5, 1.0 / B) if acc5 is not None else None
-        classifier_backward(clf, saved, logits, labels, lse, loss, self.layout, self.slabs, keeps, self.seed, 0, self.step_dev)
+        if self._side is None and os.environ.get("CLAVA_TRAIN_STREAMS", "2") != "1":
+            self._side = torch.cuda.Stream(device=self.device)
+        self._keep = classifier_backward(clf, saved, logits, labels, lse, loss, self.layout, self.slabs, keeps, self.seed, 0,
+                                         self.step_dev, side=self._side)
         self.step_dev += 1
         return loss, a1, a5, (saved, logits, rows, lse, acc1, acc5, x_t, t)
 

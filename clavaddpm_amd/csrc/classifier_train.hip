@@ -5,18 +5,24 @@
 // One hidden block of the classifier is  a = act(Linear(h_prev));  y = BN_train(a);  h = dropout(y).
 //   forward :  bn_stats (column mean / M2 per batch slab)  ->  bn_apply (combine slabs, normalise, scale/shift, dropout,
 //              running-statistics update)
-//   backward:  bn_bwd_reduce (column sums of dy and dy*xhat per batch slab, written straight into the gradient slabs of
-//              beta / gamma)  ->  bn_bwd_apply (dz = act'(a) * gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)))
+//   backward:  bn_bwd_reduce (column sums of dy and dy*xhat per batch slab)  ->  bn_bwd_apply (combine slabs, publish
+//              dgamma / dbeta, dz = act'(a) * gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)))
 // Only `a` is kept from the forward: xhat is recomputed from (a, mean, invstd) and the dropout mask from the counter-based
 // generator (or read from an injected byte mask in parity tests).  Every reduction has a fixed order (bitwise
-// reproducible, no atomics).  All kernels are HBM/L2-bound streams over [B, C] float32.
+// reproducible, no atomics).
+//
+// All four kernels are HBM/L2-bound streams over [B, C] float32.  A workgroup owns 128 columns (512 contiguous bytes per
+// row: 32 lanes x float4, two rows per wavefront) and a batch slab; slabs are sized so that even the 1024-wide layer at
+// batch 4096 launches 512 workgroups.
 #include "common.h"
 #include "rng.h"
 #include "clava_hip.h"
 
 namespace {
 
-constexpr int BN_MAX_SLABS = 32;
+constexpr int BN_MAX_SLABS = 64;
+constexpr int BN_COLS = 128;       // columns per workgroup
+constexpr int BN_ROWS = 64;        // rows per workgroup of the elementwise kernels
 
 struct BnFwdArgs {
     const float* a; int lda;          // [B, C] post-activation input of the BatchNorm
@@ -35,6 +41,28 @@ struct BnFwdArgs {
 
 __device__ __forceinline__ int slab_rows(int B, int S) { return (B + S - 1) / S; }
 
+// 4 consecutive columns [col, col+4) of row r; VEC: one 16-byte access (C % 4 == 0, 16-byte aligned rows)
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int ld, int r, int col, int C) {
+    if (VEC) return *reinterpret_cast<const float4*>(p + (size_t)r * ld + col);
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* q = p + (size_t)r * ld + col;
+    if (col + 0 < C) v.x = q[0];
+    if (col + 1 < C) v.y = q[1];
+    if (col + 2 < C) v.z = q[2];
+    if (col + 3 < C) v.w = q[3];
+    return v;
+}
+template <bool VEC>
+__device__ __forceinline__ void store4(float* __restrict__ p, int ld, int r, int col, int C, float4 v) {
+    if (VEC) { *reinterpret_cast<float4*>(p + (size_t)r * ld + col) = v; return; }
+    float* q = p + (size_t)r * ld + col;
+    if (col + 0 < C) q[0] = v.x;
+    if (col + 1 < C) q[1] = v.y;
+    if (col + 2 < C) q[2] = v.z;
+    if (col + 3 < C) q[3] = v.w;
+}
+
 // keep flags of the 4 consecutive columns [c4*4, c4*4+4) of row r
 __device__ __forceinline__ void keep4(const unsigned char* mask, int ldmask, float p, unsigned long long seed, unsigned int step,
                                       unsigned int layer, int r, int c4, int C, bool k[4]) {
@@ -51,200 +79,268 @@ __device__ __forceinline__ void keep4(const unsigned char* mask, int ldmask, flo
     }
 }
 
-// grid (ceil(C/32), S), 256 threads = 8 column groups (4 columns each) x 32 row lanes
+// LDS reduction of per-thread float4 partials over the 8 row lanes of a workgroup; result valid in threads < 32
+__device__ __forceinline__ float4 reduce_rows(float4 v, float (*sh)[BN_COLS + 4]) {
+    const int cg = threadIdx.x & 31, q = threadIdx.x >> 5;
+    *reinterpret_cast<float4*>(&sh[q][cg * 4]) = v;
+    __syncthreads();
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 u = *reinterpret_cast<const float4*>(&sh[i][cg * 4]);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+    }
+    __syncthreads();
+    return t;
+}
+
+// grid (ceil(C/128), S), 256 threads = 32 column groups (4 columns each) x 8 row lanes
+template <bool VEC>
 __global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs g) {
-    __shared__ float part[32][33];
-    __shared__ float mean_s[32];
-    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;
-    const int col = blockIdx.x * 32 + cg * 4;
+    __shared__ __align__(16) float sh[8][BN_COLS + 4];
+    __shared__ __align__(16) float mean_s[BN_COLS];
+    const int cg = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int col = blockIdx.x * BN_COLS + cg * 4;
+    const bool live = col < g.C;
     const int rp = slab_rows(g.B, g.S);
     const int r0 = blockIdx.y * rp, r1 = min(g.B, r0 + rp);
     const int n = r1 - r0;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + q; r < r1; r += 32)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (col + c < g.C) acc[c] += g.a[(size_t)r * g.lda + col + c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) part[q][cg * 4 + c] = acc[c];
-    __syncthreads();
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int r = r0 + q; r < r1; r += 8) {
+            const float4 v = load4<VEC>(g.a, g.lda, r, col, g.C);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    float4 t = reduce_rows(acc, sh);
     if (threadIdx.x < 32) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
-        mean_s[threadIdx.x] = n > 0 ? t / (float)n : 0.f;
+        const float inv_n = n > 0 ? 1.0f / (float)n : 0.f;
+        t.x *= inv_n; t.y *= inv_n; t.z *= inv_n; t.w *= inv_n;
+        *reinterpret_cast<float4*>(&mean_s[cg * 4]) = t;
     }
     __syncthreads();
-    float mu[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { mu[c] = mean_s[cg * 4 + c]; acc[c] = 0.f; }
-    for (int r = r0 + q; r < r1; r += 32)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (col + c < g.C) {
-                const float d = g.a[(size_t)r * g.lda + col + c] - mu[c];
-                acc[c] += d * d;
-            }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) part[q][cg * 4 + c] = acc[c];
-    __syncthreads();
-    if (threadIdx.x < 32 && blockIdx.x * 32 + threadIdx.x < g.C) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
-        const int c = blockIdx.x * 32 + threadIdx.x;
-        g.part[(size_t)blockIdx.y * g.C + c] = mean_s[threadIdx.x];
-        g.part[(size_t)(g.S + blockIdx.y) * g.C + c] = t;
+    const float4 mu = *reinterpret_cast<const float4*>(&mean_s[cg * 4]);
+    acc = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int r = r0 + q; r < r1; r += 8) {         // second pass: the slab is L2-resident
+            const float4 v = load4<VEC>(g.a, g.lda, r, col, g.C);
+            const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+            acc.x += dx * dx; acc.y += dy * dy; acc.z += dz * dz; acc.w += dw * dw;
+        }
+    t = reduce_rows(acc, sh);
+    if (threadIdx.x < 32 && live) {
+        store4<VEC>(g.part, g.C, blockIdx.y, col, g.C, mu);
+        store4<VEC>(g.part, g.C, g.S + blockIdx.y, col, g.C, t);
     }
 }
 
-// grid (ceil(C/32), ceil(B/128)): combine the slab statistics of this block's 32 columns (Chan's update, fixed order),
-// then normalise 128 rows.  Row block 0 also publishes mean / invstd and updates the running statistics
+// grid (ceil(C/128), ceil(B/64)): combine the slab statistics of this workgroup's columns (Chan's update, fixed order),
+// then normalise 64 rows.  Row block 0 also publishes mean / invstd and updates the running statistics
 // (torch: running = (1-m)*running + m*batch, with the unbiased batch variance).
+template <bool VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(BnFwdArgs g) {
-    __shared__ float s_mean[32], s_inv[32], s_gamma[32], s_beta[32];
-    if (threadIdx.x < 32) {
-        const int c = blockIdx.x * 32 + threadIdx.x;
-        float mean = 0.f, m2 = 0.f, inv = 0.f, ga = 0.f, be = 0.f;
-        if (c < g.C) {
-            const int rp = slab_rows(g.B, g.S);
-            float cnt = 0.f;
-            for (int s = 0; s < g.S; ++s) {
-                const float nb = (float)max(0, min(g.B, (s + 1) * rp) - s * rp);
-                if (nb <= 0.f) continue;
-                const float ms = g.part[(size_t)s * g.C + c], qs = g.part[(size_t)(g.S + s) * g.C + c];
-                const float tot = cnt + nb, delta = ms - mean;
-                mean += delta * (nb / tot);
-                m2 += qs + delta * delta * (cnt * nb / tot);
-                cnt = tot;
-            }
-            const float var = m2 / (float)g.B;
-            inv = 1.0f / sqrtf(var + g.eps);
-            ga = g.gamma[c]; be = g.beta[c];
-            if (blockIdx.y == 0) {
-                g.save_mean[c] = mean;
-                g.save_invstd[c] = inv;
-                if (g.run_mean) {
-                    const float unb = g.B > 1 ? m2 / (float)(g.B - 1) : var;
-                    g.run_mean[c] = (1.0f - g.momentum) * g.run_mean[c] + g.momentum * mean;
-                    g.run_var[c] = (1.0f - g.momentum) * g.run_var[c] + g.momentum * unb;
+    __shared__ __align__(16) float s_mean[BN_COLS], s_k[BN_COLS], s_beta[BN_COLS];
+    __shared__ float h_cnt[BN_COLS], h_mean[BN_COLS], h_m2[BN_COLS];
+    {
+        // two threads per column, each folds half of the slabs (loads issued eight at a time so that their latencies
+        // overlap), then thread c merges the halves: a fixed order, hence the same bits in every workgroup
+        const int cl = threadIdx.x & (BN_COLS - 1), half = threadIdx.x >> 7;
+        const int c = blockIdx.x * BN_COLS + cl;
+        const int rp = slab_rows(g.B, g.S);
+        const int sh = (g.S + 1) / 2, s0 = half * sh, s1 = min(g.S, s0 + sh);
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+        if (c < g.C)
+            for (int sb = s0; sb < s1; sb += 8) {
+                float ms[8], qs[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int s = min(sb + i, s1 - 1);
+                    ms[i] = g.part[(size_t)s * g.C + c];
+                    qs[i] = g.part[(size_t)(g.S + s) * g.C + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int s = sb + i;
+                    const float nb = s < s1 ? (float)max(0, min(g.B, (s + 1) * rp) - s * rp) : 0.f;
+                    if (nb > 0.f) {
+                        const float tot = cnt + nb, delta = ms[i] - mean;
+                        mean += delta * (nb / tot);
+                        m2 += qs[i] + delta * delta * (cnt * nb / tot);
+                        cnt = tot;
+                    }
                 }
             }
+        if (half == 1) { h_cnt[cl] = cnt; h_mean[cl] = mean; h_m2[cl] = m2; }
+        __syncthreads();
+        if (half == 0) {
+            float inv = 0.f, ga = 0.f, be = 0.f;
+            if (c < g.C) {
+                const float nb = h_cnt[cl];
+                if (nb > 0.f) {
+                    const float tot = cnt + nb, delta = h_mean[cl] - mean;
+                    mean += delta * (nb / tot);
+                    m2 += h_m2[cl] + delta * delta * (cnt * nb / tot);
+                }
+                const float var = m2 / (float)g.B;
+                inv = 1.0f / sqrtf(var + g.eps);
+                ga = g.gamma[c]; be = g.beta[c];
+                if (blockIdx.y == 0) {
+                    g.save_mean[c] = mean;
+                    g.save_invstd[c] = inv;
+                    if (g.run_mean) {
+                        const float unb = g.B > 1 ? m2 / (float)(g.B - 1) : var;
+                        g.run_mean[c] = (1.0f - g.momentum) * g.run_mean[c] + g.momentum * mean;
+                        g.run_var[c] = (1.0f - g.momentum) * g.run_var[c] + g.momentum * unb;
+                    }
+                }
+            }
+            s_mean[cl] = mean; s_k[cl] = inv * ga; s_beta[cl] = be;
         }
-        s_mean[threadIdx.x] = mean; s_inv[threadIdx.x] = inv; s_gamma[threadIdx.x] = ga; s_beta[threadIdx.x] = be;
     }
     __syncthreads();
-    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;
-    const int col = blockIdx.x * 32 + cg * 4;
+    const int cg = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int col = blockIdx.x * BN_COLS + cg * 4;
     if (col >= g.C) return;
     const float scale = g.p > 0.f ? 1.0f / (1.0f - g.p) : 1.0f;
     const unsigned int step = g.step_dev ? g.step_dev[0] : g.step;
-    const int r1 = min(g.B, (int)(blockIdx.y + 1) * 128);
-    for (int r = blockIdx.y * 128 + q; r < r1; r += 32) {
+    const float4 mu = *reinterpret_cast<const float4*>(&s_mean[cg * 4]);
+    const float4 kk = *reinterpret_cast<const float4*>(&s_k[cg * 4]);
+    const float4 be = *reinterpret_cast<const float4*>(&s_beta[cg * 4]);
+    const int r1 = min(g.B, (int)(blockIdx.y + 1) * BN_ROWS);
+    for (int r = blockIdx.y * BN_ROWS + q; r < r1; r += 8) {
         bool k[4];
         keep4(g.mask, g.ldmask, g.p, g.seed, step, g.layer, r, col >> 2, g.C, k);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (col + c < g.C) {
-                const int j = cg * 4 + c;
-                const float y = (g.a[(size_t)r * g.lda + col + c] - s_mean[j]) * s_inv[j] * s_gamma[j] + s_beta[j];
-                g.h[(size_t)r * g.ldh + col + c] = k[c] ? y * scale : 0.f;
-            }
+        const float4 v = load4<VEC>(g.a, g.lda, r, col, g.C);
+        float4 o;
+        o.x = k[0] ? ((v.x - mu.x) * kk.x + be.x) * scale : 0.f;
+        o.y = k[1] ? ((v.y - mu.y) * kk.y + be.y) * scale : 0.f;
+        o.z = k[2] ? ((v.z - mu.z) * kk.z + be.z) * scale : 0.f;
+        o.w = k[3] ? ((v.w - mu.w) * kk.w + be.w) * scale : 0.f;
+        store4<VEC>(g.h, g.ldh, r, col, g.C, o);
     }
 }
 
 struct BnBwdArgs {
     const float* dh; int lddh;        // [B, C] gradient w.r.t. the dropout output
     const float* a; int lda;          // [B, C] saved post-activation
-    int B, C, S;
+    int B, C, S;                      // S batch slabs of the reduction
+    float* part;                      // [2][S][C]: slab sums of dy, of dy*xhat
     const float* mean; const float* invstd; const float* gamma;
     const unsigned char* mask; int ldmask; float p;
     unsigned long long seed; unsigned int step, layer;
     const unsigned int* step_dev;
-    float* dgamma; float* dbeta; long long slab_stride;   // slab s at + s*slab_stride: partial column sums
+    float* dgamma; float* dbeta; long long slab_stride; int splits;   // gradient slabs: slab 0 gets the sum, the others 0
     int act; float slope;             // activation in front of the BatchNorm: act'(a) = a > 0 ? 1 : slope
     float* dz; int lddz;              // [B, C] gradient w.r.t. the Linear output
 };
 
-// grid (ceil(C/32), S): dbeta_s[c] = sum_rows dy, dgamma_s[c] = sum_rows dy*xhat over slab s
+// grid (ceil(C/128), S): slab sums of dy = dh*keep/(1-p) and of dy*xhat
+template <bool VEC>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(BnBwdArgs g) {
-    __shared__ float p0[32][33], p1[32][33];
-    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;
-    const int col = blockIdx.x * 32 + cg * 4;
+    __shared__ __align__(16) float sh[8][BN_COLS + 4];
+    const int cg = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int col = blockIdx.x * BN_COLS + cg * 4;
+    const bool live = col < g.C;
     const int rp = slab_rows(g.B, g.S);
     const int r0 = blockIdx.y * rp, r1 = min(g.B, r0 + rp);
     const float scale = g.p > 0.f ? 1.0f / (1.0f - g.p) : 1.0f;
     const unsigned int step = g.step_dev ? g.step_dev[0] : g.step;
-    float mu[4], inv[4], sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        mu[c] = col + c < g.C ? g.mean[col + c] : 0.f;
-        inv[c] = col + c < g.C ? g.invstd[col + c] : 0.f;
-    }
-    if (col < g.C)
-        for (int r = r0 + q; r < r1; r += 32) {
+    float4 sb = {0.f, 0.f, 0.f, 0.f}, sg = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float4 mu = load4<VEC>(g.mean, 0, 0, col, g.C), inv = load4<VEC>(g.invstd, 0, 0, col, g.C);
+        for (int r = r0 + q; r < r1; r += 8) {
             bool k[4];
             keep4(g.mask, g.ldmask, g.p, g.seed, step, g.layer, r, col >> 2, g.C, k);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (col + c < g.C) {
-                    const float dy = k[c] ? g.dh[(size_t)r * g.lddh + col + c] * scale : 0.f;
-                    const float xh = (g.a[(size_t)r * g.lda + col + c] - mu[c]) * inv[c];
-                    sb[c] += dy;
-                    sg[c] += dy * xh;
-                }
+            const float4 d = load4<VEC>(g.dh, g.lddh, r, col, g.C);
+            const float4 v = load4<VEC>(g.a, g.lda, r, col, g.C);
+            const float d0 = k[0] ? d.x * scale : 0.f, d1 = k[1] ? d.y * scale : 0.f;
+            const float d2 = k[2] ? d.z * scale : 0.f, d3 = k[3] ? d.w * scale : 0.f;
+            sb.x += d0; sb.y += d1; sb.z += d2; sb.w += d3;
+            sg.x += d0 * ((v.x - mu.x) * inv.x); sg.y += d1 * ((v.y - mu.y) * inv.y);
+            sg.z += d2 * ((v.z - mu.z) * inv.z); sg.w += d3 * ((v.w - mu.w) * inv.w);
         }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { p0[q][cg * 4 + c] = sb[c]; p1[q][cg * 4 + c] = sg[c]; }
-    __syncthreads();
-    if (threadIdx.x < 32 && blockIdx.x * 32 + threadIdx.x < g.C) {
-        float tb = 0.f, tg = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { tb += p0[i][threadIdx.x]; tg += p1[i][threadIdx.x]; }
-        const int c = blockIdx.x * 32 + threadIdx.x;
-        g.dbeta[(size_t)blockIdx.y * g.slab_stride + c] = tb;
-        g.dgamma[(size_t)blockIdx.y * g.slab_stride + c] = tg;
+    }
+    const float4 tb = reduce_rows(sb, sh);
+    const float4 tg = reduce_rows(sg, sh);
+    if (threadIdx.x < 32 && live) {
+        store4<VEC>(g.part, g.C, blockIdx.y, col, g.C, tb);
+        store4<VEC>(g.part, g.C, g.S + blockIdx.y, col, g.C, tg);
     }
 }
 
-// grid (ceil(C/32), ceil(B/128))
+// grid (ceil(C/128), ceil(B/64))
+template <bool VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs g) {
-    __shared__ float s_mean[32], s_inv[32], s_k[32], s_db[32], s_dg[32];
-    if (threadIdx.x < 32) {
-        const int c = blockIdx.x * 32 + threadIdx.x;
-        float db = 0.f, dg = 0.f, mean = 0.f, inv = 0.f, ga = 0.f;
-        if (c < g.C) {
-            for (int s = 0; s < g.S; ++s) {
-                db += g.dbeta[(size_t)s * g.slab_stride + c];
-                dg += g.dgamma[(size_t)s * g.slab_stride + c];
+    __shared__ __align__(16) float s_mean[BN_COLS], s_inv[BN_COLS], s_k[BN_COLS], s_db[BN_COLS], s_dg[BN_COLS];
+    __shared__ float h_db[BN_COLS], h_dg[BN_COLS];
+    {
+        const int cl = threadIdx.x & (BN_COLS - 1), half = threadIdx.x >> 7;
+        const int c = blockIdx.x * BN_COLS + cl;
+        const int sh = (g.S + 1) / 2, s0 = half * sh, s1 = min(g.S, s0 + sh);
+        float db = 0.f, dg = 0.f;
+        if (c < g.C)
+            for (int sb = s0; sb < s1; sb += 8) {
+                float b8[8], g8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int s = min(sb + i, s1 - 1);
+                    b8[i] = g.part[(size_t)s * g.C + c];
+                    g8[i] = g.part[(size_t)(g.S + s) * g.C + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (sb + i < s1) { db += b8[i]; dg += g8[i]; }
             }
-            mean = g.mean[c]; inv = g.invstd[c]; ga = g.gamma[c];
+        if (half == 1) { h_db[cl] = db; h_dg[cl] = dg; }
+        __syncthreads();
+        if (half == 0) {
+            float mean = 0.f, inv = 0.f, ga = 0.f;
+            if (c < g.C) {
+                db += h_db[cl]; dg += h_dg[cl];
+                mean = g.mean[c]; inv = g.invstd[c]; ga = g.gamma[c];
+                if (blockIdx.y == 0) {
+                    g.dbeta[c] = db;
+                    g.dgamma[c] = dg;
+                    for (int s = 1; s < g.splits; ++s) {
+                        g.dbeta[(size_t)s * g.slab_stride + c] = 0.f;
+                        g.dgamma[(size_t)s * g.slab_stride + c] = 0.f;
+                    }
+                }
+            }
+            s_mean[cl] = mean; s_inv[cl] = inv; s_k[cl] = ga * inv;
+            s_db[cl] = db / (float)g.B; s_dg[cl] = dg / (float)g.B;
         }
-        s_mean[threadIdx.x] = mean; s_inv[threadIdx.x] = inv; s_k[threadIdx.x] = ga * inv;
-        s_db[threadIdx.x] = db / (float)g.B; s_dg[threadIdx.x] = dg / (float)g.B;
     }
     __syncthreads();
-    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;
-    const int col = blockIdx.x * 32 + cg * 4;
+    const int cg = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int col = blockIdx.x * BN_COLS + cg * 4;
     if (col >= g.C) return;
     const float scale = g.p > 0.f ? 1.0f / (1.0f - g.p) : 1.0f;
     const unsigned int step = g.step_dev ? g.step_dev[0] : g.step;
-    const int r1 = min(g.B, (int)(blockIdx.y + 1) * 128);
-    for (int r = blockIdx.y * 128 + q; r < r1; r += 32) {
+    const float4 mu = *reinterpret_cast<const float4*>(&s_mean[cg * 4]);
+    const float4 inv = *reinterpret_cast<const float4*>(&s_inv[cg * 4]);
+    const float4 kk = *reinterpret_cast<const float4*>(&s_k[cg * 4]);
+    const float4 mb = *reinterpret_cast<const float4*>(&s_db[cg * 4]);
+    const float4 mg = *reinterpret_cast<const float4*>(&s_dg[cg * 4]);
+    const bool has_act = g.act != CLAVA_ACT_NONE;
+    const float slope = g.slope;
+    const int r1 = min(g.B, (int)(blockIdx.y + 1) * BN_ROWS);
+    for (int r = blockIdx.y * BN_ROWS + q; r < r1; r += 8) {
         bool k[4];
         keep4(g.mask, g.ldmask, g.p, g.seed, step, g.layer, r, col >> 2, g.C, k);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (col + c < g.C) {
-                const int j = cg * 4 + c;
-                const float av = g.a[(size_t)r * g.lda + col + c];
-                const float dy = k[c] ? g.dh[(size_t)r * g.lddh + col + c] * scale : 0.f;
-                const float xh = (av - s_mean[j]) * s_inv[j];
-                float d = s_k[j] * (dy - s_db[j] - xh * s_dg[j]);
-                if (g.act != CLAVA_ACT_NONE) d *= av > 0.f ? 1.0f : g.slope;
-                g.dz[(size_t)r * g.lddz + col + c] = d;
-            }
+        const float4 d = load4<VEC>(g.dh, g.lddh, r, col, g.C);
+        const float4 v = load4<VEC>(g.a, g.lda, r, col, g.C);
+        float4 o;
+        o.x = kk.x * ((k[0] ? d.x * scale : 0.f) - mb.x - ((v.x - mu.x) * inv.x) * mg.x);
+        o.y = kk.y * ((k[1] ? d.y * scale : 0.f) - mb.y - ((v.y - mu.y) * inv.y) * mg.y);
+        o.z = kk.z * ((k[2] ? d.z * scale : 0.f) - mb.z - ((v.z - mu.z) * inv.z) * mg.z);
+        o.w = kk.w * ((k[3] ? d.w * scale : 0.f) - mb.w - ((v.w - mu.w) * inv.w) * mg.w);
+        if (has_act) {
+            o.x *= v.x > 0.f ? 1.0f : slope; o.y *= v.y > 0.f ? 1.0f : slope;
+            o.z *= v.z > 0.f ? 1.0f : slope; o.w *= v.w > 0.f ? 1.0f : slope;
+        }
+        store4<VEC>(g.dz, g.lddz, r, col, g.C, o);
     }
 }
 
@@ -307,12 +403,14 @@ __global__ void __launch_bounds__(256) ce_grad_kernel(const float* __restrict__ 
 }
 
 int pick_slabs(int B, int C) {
-    const int colblocks = (C + 31) / 32;
+    const int colblocks = (C + BN_COLS - 1) / BN_COLS;
     int s = (512 + colblocks - 1) / colblocks;
     s = min(s, BN_MAX_SLABS);
-    s = min(s, max(1, B / 64));
+    s = min(s, max(1, B / 32));
     return max(1, s);
 }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -323,8 +421,7 @@ long long clava_bn_workspace_floats(int C) { return 2LL * BN_MAX_SLABS * (long l
 int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, float p, const unsigned char* keep_mask,
                                int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
-                               float* workspace,
-                               float* save_mean, float* save_invstd, float* h, int ldh, void* stream) {
+                               float* workspace, float* save_mean, float* save_invstd, float* h, int ldh, void* stream) {
     CLAVA_CHECK_ARG(a && gamma && beta && workspace && save_mean && save_invstd && h && B > 0 && C > 0 && lda >= C && ldh >= C,
                     "bn_dropout_train: bad arguments");
     CLAVA_CHECK_ARG(p >= 0.f && p < 1.f && (!keep_mask || ldmask >= C) && (!running_mean == !running_var) && layer < 32,
@@ -334,14 +431,18 @@ int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const floa
     g.run_mean = running_mean; g.run_var = running_var; g.momentum = momentum; g.eps = eps; g.save_mean = save_mean;
     g.save_invstd = save_invstd; g.h = h; g.ldh = ldh; g.mask = keep_mask; g.ldmask = ldmask; g.p = p; g.seed = seed; g.step = step;
     g.step_dev = step_dev; g.layer = layer;
+    const bool vec = C % 4 == 0 && lda % 4 == 0 && ldh % 4 == 0 && aligned16(a) && aligned16(h) && aligned16(workspace);
+    const dim3 gs((C + BN_COLS - 1) / BN_COLS, g.S), ga((C + BN_COLS - 1) / BN_COLS, (B + BN_ROWS - 1) / BN_ROWS);
     {
-        ProfScope prof(PROF_MISC, 0.0, 8.0 * B * C, (hipStream_t)stream);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 31) / 32, g.S), dim3(256), 0, (hipStream_t)stream, g);
+        ProfScope prof(PROF_BN, 0.0, 8.0 * B * C, (hipStream_t)stream);
+        if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, gs, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(bn_stats_kernel<false>, gs, dim3(256), 0, (hipStream_t)stream, g);
         CLAVA_CHECK_LAUNCH("clava_bn_dropout_train_f32(stats)");
     }
     {
-        ProfScope prof(PROF_MISC, 0.0, 8.0 * B * C, (hipStream_t)stream);
-        hipLaunchKernelGGL(bn_apply_kernel, dim3((C + 31) / 32, (B + 127) / 128), dim3(256), 0, (hipStream_t)stream, g);
+        ProfScope prof(PROF_BN, 0.0, 8.0 * B * C, (hipStream_t)stream);
+        if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, ga, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(bn_apply_kernel<false>, ga, dim3(256), 0, (hipStream_t)stream, g);
         CLAVA_CHECK_LAUNCH("clava_bn_dropout_train_f32(apply)");
     }
     return CLAVA_OK;
@@ -350,25 +451,30 @@ int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const floa
 int clava_bn_dropout_backward_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
                                   const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
                                   int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
-                                  int act, float slope,
-                                  int splits, float* dgamma_slabs, float* dbeta_slabs, long long slab_stride, float* dz,
-                                  int lddz, void* stream) {
-    CLAVA_CHECK_ARG(dh && a && save_mean && save_invstd && gamma && dgamma_slabs && dbeta_slabs && dz && B > 0 && C > 0 &&
+                                  int act, float slope, float* workspace, int splits, float* dgamma_slabs, float* dbeta_slabs,
+                                  long long slab_stride, float* dz, int lddz, void* stream) {
+    CLAVA_CHECK_ARG(dh && a && save_mean && save_invstd && gamma && workspace && dgamma_slabs && dbeta_slabs && dz && B > 0 && C > 0 &&
                         lddh >= C && lda >= C && lddz >= C && splits >= 1 && splits <= 64,
                     "bn_dropout_backward: bad arguments");
     CLAVA_CHECK_ARG(p >= 0.f && p < 1.f && (!keep_mask || ldmask >= C) && layer < 32, "bn_dropout_backward: bad dropout arguments");
     BnBwdArgs g;
-    g.dh = dh; g.lddh = lddh; g.a = a; g.lda = lda; g.B = B; g.C = C; g.S = splits; g.mean = save_mean; g.invstd = save_invstd;
-    g.gamma = gamma; g.mask = keep_mask; g.ldmask = ldmask; g.p = p; g.seed = seed; g.step = step; g.step_dev = step_dev; g.layer = layer;
-    g.dgamma = dgamma_slabs; g.dbeta = dbeta_slabs; g.slab_stride = slab_stride; g.act = act; g.slope = slope; g.dz = dz; g.lddz = lddz;
+    g.dh = dh; g.lddh = lddh; g.a = a; g.lda = lda; g.B = B; g.C = C; g.S = pick_slabs(B, C); g.part = workspace;
+    g.mean = save_mean; g.invstd = save_invstd; g.gamma = gamma; g.mask = keep_mask; g.ldmask = ldmask; g.p = p; g.seed = seed;
+    g.step = step; g.step_dev = step_dev; g.layer = layer; g.dgamma = dgamma_slabs; g.dbeta = dbeta_slabs;
+    g.slab_stride = slab_stride; g.splits = splits; g.act = act; g.slope = slope; g.dz = dz; g.lddz = lddz;
+    const bool vec = C % 4 == 0 && lda % 4 == 0 && lddh % 4 == 0 && lddz % 4 == 0 && aligned16(a) && aligned16(dh) && aligned16(dz) &&
+                     aligned16(workspace) && aligned16(save_mean) && aligned16(save_invstd);
+    const dim3 gs((C + BN_COLS - 1) / BN_COLS, g.S), ga((C + BN_COLS - 1) / BN_COLS, (B + BN_ROWS - 1) / BN_ROWS);
     {
-        ProfScope prof(PROF_MISC, 0.0, 8.0 * B * C, (hipStream_t)stream);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, g);
+        ProfScope prof(PROF_BN, 0.0, 8.0 * B * C, (hipStream_t)stream);
+        if (vec) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, gs, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, gs, dim3(256), 0, (hipStream_t)stream, g);
         CLAVA_CHECK_LAUNCH("clava_bn_dropout_backward_f32(reduce)");
     }
     {
-        ProfScope prof(PROF_MISC, 0.0, 12.0 * B * C, (hipStream_t)stream);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((C + 31) / 32, (B + 127) / 128), dim3(256), 0, (hipStream_t)stream, g);
+        ProfScope prof(PROF_BN, 0.0, 12.0 * B * C, (hipStream_t)stream);
+        if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, ga, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, ga, dim3(256), 0, (hipStream_t)stream, g);
         CLAVA_CHECK_LAUNCH("clava_bn_dropout_backward_f32(apply)");
     }
     return CLAVA_OK;

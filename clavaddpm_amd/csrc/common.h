@@ -33,7 +33,7 @@ void clava_set_error(const char* fmt, ...);
 enum ProfFamily {
     PROF_GEMM_NT_128 = 0, PROF_GEMM_NT_64, PROF_GEMM_NT_128_BN, PROF_GEMM_NT_64_BN, PROF_GEMM_NN_128, PROF_GEMM_NN_64,
     PROF_GEMM_TN_128, PROF_GEMM_TN_64,
-    PROF_GAUSS_STEP, PROF_MULTI_STEP, PROF_SELECT_GRAD, PROF_MISC, PROF_LOSS, PROF_ADAMW, PROF_GMM,
+    PROF_GAUSS_STEP, PROF_MULTI_STEP, PROF_SELECT_GRAD, PROF_MISC, PROF_LOSS, PROF_ADAMW, PROF_GMM, PROF_BN,
     PROF_GEMM_F16X3,                                   // first of PROF_GEMM_F16X3_CFGS families, one per tile configuration
     PROF_N_FAMILIES = PROF_GEMM_F16X3 + 8
 };

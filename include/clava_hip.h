@@ -319,14 +319,15 @@ int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const floa
                                float* workspace,
                                float* save_mean, float* save_invstd, float* h, int ldh, void* stream);
 /* Backward of the block above, from dh (gradient w.r.t. the dropout output) to dz (gradient w.r.t. the Linear output):
- * dy = dh * keep/(1-p); dbeta = sum_b dy, dgamma = sum_b dy*xhat, written as `splits` partial sums over batch ranges at
- * dbeta_slabs / dgamma_slabs + s*slab_stride (the layout clava_adamw_ema_f32 sums); dz = act'(a) * gamma*invstd *
+ * dy = dh * keep/(1-p); dbeta = sum_b dy, dgamma = sum_b dy*xhat (summed in a fixed order through `workspace`,
+ * clava_bn_workspace_floats(C) floats) land in slab 0 of dbeta_slabs / dgamma_slabs, slabs 1..splits-1 (at
+ * + s*slab_stride, the layout clava_adamw_ema_f32 sums) are zeroed; dz = act'(a) * gamma*invstd *
  * (dy - dbeta/B - xhat*dgamma/B) with act'(a) = a > 0 ? 1 : slope (act = CLAVA_ACT_NONE: no activation factor).
  * Replaces autograd's backward through model.{j+1..j+3} of the reference Classifier. */
 int clava_bn_dropout_backward_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
                                   const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
                                   int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
-                                  int act, float slope,
+                                  int act, float slope, float* workspace,
                                   int splits, float* dgamma_slabs, float* dbeta_slabs, long long slab_stride, float* dz,
                                   int lddz, void* stream);
 /* F.cross_entropy(logits, labels, reduction='none') per row (pipeline_utils.py:683) with the row's logsumexp and the

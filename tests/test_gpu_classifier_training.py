@@ -67,11 +67,11 @@ def test_bn_dropout_block_matches_torch(B, C, act):
     assert relerr(rm.cpu(), 0.9 * rm0.double() + 0.1 * mean_ref) < 1e-5
     assert relerr(rv.cpu(), 0.9 * rv0.double() + 0.1 * var_ref * B / (B - 1)) < 1e-5
     S = 8
-    slabs = torch.zeros(S, 2 * C, device=DEV)
+    slabs = torch.full((S, 2 * C), 7.0, device=DEV)          # slabs 1.. must come back zeroed
     dz = torch.empty(B, C, device=DEV)
     check(lib().clava_bn_dropout_backward_f32(ptr(dhd), c_int(C), ptr(ad), c_int(C), c_int(B), c_int(C), ptr(mean), ptr(inv), ptr(gd),
                                               c_float(0.5), ptr(kd), c_int(C), ctypes.c_ulonglong(0), ctypes.c_uint(0), None,
-                                              ctypes.c_uint(0), c_int(act), c_float(slope), c_int(S), ptr(slabs), ptr(slabs[:, C:]),
+                                              ctypes.c_uint(0), c_int(act), c_float(slope), ptr(ws), c_int(S), ptr(slabs), ptr(slabs[:, C:]),
                                               ctypes.c_longlong(2 * C), ptr(dz), c_int(C), stream_ptr()), "bn bwd")
     tot = slabs.sum(0).cpu()
     assert relerr(tot[:C], dg_ref) < 1e-4
@@ -108,7 +108,7 @@ def test_generated_dropout_masks_agree_between_forward_and_backward():
         dz = torch.empty(B, C, device=DEV)
         check(lib().clava_bn_dropout_backward_f32(ptr(dh), c_int(C), ptr(a), c_int(C), c_int(B), c_int(C), ptr(mean), ptr(inv), ptr(gamma),
                                                   c_float(0.5), ptr(kd), c_int(C if kd is not None else 0), ctypes.c_ulonglong(99),
-                                                  ctypes.c_uint(7), None, ctypes.c_uint(2), c_int(0), c_float(0.0), c_int(8), ptr(slabs),
+                                                  ctypes.c_uint(7), None, ctypes.c_uint(2), c_int(0), c_float(0.0), ptr(ws), c_int(8), ptr(slabs),
                                                   ptr(slabs[:, C:]), ctypes.c_longlong(2 * C), ptr(dz), c_int(C), stream_ptr()), "bn bwd")
         res.append((dz.clone(), slabs.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
