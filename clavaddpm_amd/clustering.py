@@ -1,9 +1,11 @@
-"""GMM E-step of the parent-child clustering stage on the HIP library.
+"""GMM E-step and M-step of the parent-child clustering stage on the HIP library.
 
-`gmm_estep` is the raw operator; `HipGaussianMixture` plugs it into scikit-learn's `GaussianMixture`
+`gmm_estep` / `gmm_mstep` are the raw operators; `HipGaussianMixture` plugs them into scikit-learn's `GaussianMixture`
 (`pipeline_modules.py:268-277` constructs one with covariance_type='diag', init_params='k-means++', tol=1e-4) by
-overriding only the E-step pieces (`_estimate_log_prob_resp`, `predict`): k-means++ initialisation and the M-step stay
-scikit-learn's host code (DESIGN.md "next").
+overriding the E-step and M-step pieces (`_e_step`, `_m_step`, `_compute_lower_bound`, `_estimate_log_prob_resp`,
+`predict`): during `fit` the data matrix, the responsibilities and the per-row log-likelihoods never leave the device;
+one small packed buffer (the new parameters, the lower bound and a validity flag) comes back per EM iteration.
+k-means++ initialisation stays scikit-learn's host code.
 """
 import ctypes
 
@@ -41,6 +43,51 @@ def gmm_estep(X, weights, means, precisions_chol, want_resp=True, want_labels=Tr
     return lpn, resp, labels
 
 
+def gmm_mstep(X, log_resp, log_prob_norm=None, reg_covar=1e-6, workspace=None):
+    """scikit-learn's diag M-step on the device.  X [N,d], log_resp [N,k], log_prob_norm [N] or None: float64 device
+    tensors.  Returns one packed float64 device tensor [2 + k + 3*k*d] = (lower bound, bad-covariance flag, weights [k],
+    means [k,d], covariances [k,d], precisions_chol [k,d]); `unpack_mstep` splits a (host or device) copy of it."""
+    _lib.require_cuda(X, log_resp)
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    log_resp = log_resp.contiguous()
+    N, d = X.shape
+    k = log_resp.shape[1]
+    dev = X.device
+    if workspace is None:
+        need = lib().clava_gmm_mstep_workspace_doubles
+        need.restype = ctypes.c_longlong
+        workspace = torch.empty(int(need(c_int(k), c_int(d))), device=dev, dtype=torch.float64)
+    out = torch.empty(2 + k + 3 * k * d, device=dev, dtype=torch.float64)
+    st, w, m, cv, pc = unpack_mstep(out, k, d)
+    check(lib().clava_gmm_mstep_f64(ptr(X), c_ll(X.stride(0)), c_ll(N), c_int(d), c_int(k), ptr(log_resp), ptr(log_prob_norm),
+                                    ctypes.c_double(reg_covar), ptr(workspace), ptr(w), ptr(m), ptr(cv), ptr(pc), ptr(st),
+                                    stream_ptr()), "clava_gmm_mstep_f64")
+    return out
+
+
+def unpack_mstep(buf, k, d):
+    """(stats [2], weights [k], means [k,d], covariances [k,d], precisions_chol [k,d]) views of a packed M-step result."""
+    o = 2
+    st = buf[:2]
+    w = buf[o:o + k]; o += k
+    m = buf[o:o + k * d].reshape(k, d); o += k * d
+    cv = buf[o:o + k * d].reshape(k, d); o += k * d
+    pc = buf[o:o + k * d].reshape(k, d)
+    return st, w, m, cv, pc
+
+
+class _DeviceResponsibilities:
+    """What `_e_step` hands to `_m_step` during `fit`: device-resident log_resp / log_prob_norm / labels.  `argmax` serves
+    the last line of scikit-learn's `fit_predict` (`log_resp.argmax(axis=1)`)."""
+
+    def __init__(self, log_resp, log_prob_norm, labels):
+        self.log_resp, self.log_prob_norm, self.labels = log_resp, log_prob_norm, labels
+
+    def argmax(self, axis=1):
+        return self.labels.cpu().numpy().astype(np.int64)
+
+
 def _sk_gaussian_mixture():
     from sklearn.mixture import GaussianMixture
     return GaussianMixture
@@ -74,6 +121,50 @@ class HipGaussianMixture(_sk_gaussian_mixture()):
             raise NotImplementedError("HipGaussianMixture implements covariance_type='diag' (what ClavaDDPM uses)")
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
         return f(self.weights_), f(self.means_), f(self.precisions_cholesky_)
+
+    # ---- EM loop of BaseMixture.fit_predict: everything of size N stays on the device
+    def _fresh_dev_params(self):
+        """Device copies of the parameters: those of the last device M-step if the numpy attributes are still the arrays
+        it produced, else an upload."""
+        c = getattr(self, "_dev_params", None)
+        if c is not None and c[0] is self.weights_ and c[1] is self.means_ and c[2] is self.precisions_cholesky_:
+            return c[3], c[4], c[5]
+        return self._params_dev()
+
+    def _e_step(self, X):
+        w, m, pc = self._fresh_dev_params()
+        lpn, resp, labels = gmm_estep(self._device_x(X), w, m, pc, want_resp=True, want_labels=True)
+        r = _DeviceResponsibilities(resp, lpn, labels)
+        return r, r
+
+    def _m_step(self, X, log_resp):
+        if not isinstance(log_resp, _DeviceResponsibilities):       # a caller outside fit(): scikit-learn's host M-step
+            self._lower = None
+            return super()._m_step(X, log_resp)
+        Xd = self._device_x(X)
+        k, d = log_resp.log_resp.shape[1], Xd.shape[1]
+        ws = getattr(self, "_mstep_ws", None)
+        if ws is None or ws[0] != (k, d, str(Xd.device)):
+            need = lib().clava_gmm_mstep_workspace_doubles
+            need.restype = ctypes.c_longlong
+            ws = ((k, d, str(Xd.device)), torch.empty(int(need(c_int(k), c_int(d))), device=Xd.device, dtype=torch.float64))
+            self._mstep_ws = ws
+        packed = gmm_mstep(Xd, log_resp.log_resp, log_resp.log_prob_norm, self.reg_covar, workspace=ws[1])
+        host = packed.cpu().numpy()                                  # the one synchronisation of an EM iteration
+        st, w, m, cv, pc = unpack_mstep(host, k, d)
+        if st[1] != 0.0:
+            raise ValueError("Fitting the mixture model failed because some components have ill-defined empirical "
+                             "covariance (for instance caused by singleton or collapsed samples). Try to decrease the "
+                             "number of components, increase reg_covar, or scale the input data.")
+        self.weights_, self.means_, self.covariances_, self.precisions_cholesky_ = w.copy(), m.copy(), cv.copy(), pc.copy()
+        _, dw, dm, _, dpc = unpack_mstep(packed, k, d)
+        self._dev_params = (self.weights_, self.means_, self.precisions_cholesky_, dw, dm, dpc)
+        self._lower = float(st[0])
+
+    def _compute_lower_bound(self, log_resp, log_prob_norm):
+        if isinstance(log_prob_norm, _DeviceResponsibilities):
+            return self._lower
+        return super()._compute_lower_bound(log_resp, log_prob_norm)
 
     def _estimate_log_prob_resp(self, X):
         w, m, pc = self._params_dev()

@@ -350,6 +350,185 @@ int launch_resident_ct(const GmmArgs& g, int n_chunks, hipStream_t st) {
     return launch_resident<CT, 4>(g, st);
 }
 
+// ---------------------------------------------------------------------------------------------------- M-step
+// scikit-learn's `_m_step` for 'diag' (`_estimate_gaussian_parameters`, `_estimate_gaussian_covariances_diag`,
+// `_compute_precision_cholesky`): with resp = exp(log_resp),
+//   nk[c] = sum_n resp + 10 eps;  means = resp^T X / nk;  cov = resp^T X^2 / nk - means^2 + reg_covar;
+//   weights = nk / sum(nk);  precisions_chol = 1 / sqrt(cov);  and the EM lower bound mean_n log_prob_norm.
+// The two k x N x d products run on v_mfma_f64_16x16x4_f64 with the SAMPLE axis as the contraction: a K-slice is four
+// samples, A[c][n] = resp (lane: component lane & 15, sample lane >> 4), B[n][j] = X or X^2 (lane: sample lane >> 4,
+// feature lane & 15), so both operands are read straight from HBM in 128-byte row segments, exponentiated in registers,
+// and never staged.  A wavefront owns 16-row groups (4 K-slices; the next group's loads are issued before the current
+// group's products) and keeps the 2 x CT x 2 accumulator tiles of a 32-feature chunk in registers for the whole launch;
+// workgroups reduce their four wavefronts through LDS tile by tile and write one partial set each; two small kernels
+// add the partial sets in a fixed order and turn the totals into parameters.  Traffic: log_resp once per 32-feature
+// chunk, X once.
+struct GmmMArgs {
+    const double* X; long long ldx; long long N; int d, k;
+    const double* log_resp;         // [N, k]
+    const double* log_prob_norm;    // [N] or null
+    double* part;                   // [G][KP*DP*2 + KP + 1] partial sets
+    int KP, DP;                     // padded k (CT*16), padded d (32 * chunks)
+    long long set_stride;
+};
+
+template <int CT>
+__global__ void __launch_bounds__(256) gmm_mstep_kernel(GmmMArgs g) {
+    __shared__ double red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int j0 = blockIdx.y * 32;
+    const bool first_chunk = blockIdx.y == 0;
+    f64x4 s1[CT][2], s2[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) { s1[ct][jt] = {0.0, 0.0, 0.0, 0.0}; s2[ct][jt] = {0.0, 0.0, 0.0, 0.0}; }
+    double nk[CT], lpn = 0.0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) nk[ct] = 0.0;
+    bool cv[CT], jv[2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) cv[ct] = ct * 16 + c16 < g.k;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) jv[jt] = j0 + jt * 16 + c16 < g.d;
+
+    const long long groups = (g.N + 15) / 16;
+    const long long stride = (long long)gridDim.x * 4;
+    double la[4][CT], xb[4][2], lp[4];
+    auto load = [&](long long gi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long n = gi * 16 + q + 4 * r;
+            const bool ok = n < g.N;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                la[r][ct] = (ok && cv[ct]) ? g.log_resp[(size_t)n * g.k + ct * 16 + c16] : -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) xb[r][jt] = (ok && jv[jt]) ? g.X[(size_t)n * g.ldx + j0 + jt * 16 + c16] : 0.0;
+            lp[r] = (ok && first_chunk && c16 == 0 && g.log_prob_norm) ? g.log_prob_norm[n] : 0.0;
+        }
+    };
+    long long gi = (long long)blockIdx.x * 4 + wave;
+    if (gi < groups) load(gi);
+    for (; gi < groups; gi += stride) {
+        double a[4][CT], x[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) a[r][ct] = la[r][ct] == -INFINITY ? 0.0 : exp_nonpos(la[r][ct]);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) x[r][jt] = xb[r][jt];
+            lpn += lp[r];
+        }
+        if (gi + stride < groups) load(gi + stride);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                nk[ct] += a[r][ct];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    s1[ct][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][ct], x[r][jt], s1[ct][jt], 0, 0, 0);
+                    s2[ct][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][ct], x[r][jt] * x[r][jt], s2[ct][jt], 0, 0, 0);
+                }
+            }
+    }
+    // ---- workgroup reduction, one accumulator tile at a time; D map: component = (lane >> 4) + 4 * reg, feature = lane & 15
+    double* set = g.part + (size_t)blockIdx.x * g.set_stride;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const f64x4 v = t == 0 ? s1[ct][jt] : s2[ct][jt];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave][e * 64 + lane] = v[e];
+                __syncthreads();
+                {
+                    const int e = tid >> 6, l = tid & 63;
+                    const double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+                    const int comp = ct * 16 + (l >> 4) + 4 * e, feat = j0 + jt * 16 + (l & 15);
+                    set[((size_t)t * g.KP + comp) * g.DP + feat] = sum;
+                }
+                __syncthreads();
+            }
+    if (first_chunk) {
+        // nk: lane (q, c16) holds the partial of component ct*16 + c16 over its samples; lpn: lanes with c16 == 0
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            red[wave][lane] = nk[ct];
+            __syncthreads();
+            if (tid < 16) {
+                double sum = 0.0;
+                for (int w = 0; w < 4; ++w)
+                    for (int qq = 0; qq < 4; ++qq) sum += red[w][qq * 16 + tid];
+                set[(size_t)2 * g.KP * g.DP + ct * 16 + tid] = sum;
+            }
+            __syncthreads();
+        }
+        red[wave][lane] = lpn;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < 4; ++w)
+                for (int qq = 0; qq < 4; ++qq) sum += red[w][qq * 16];
+            set[(size_t)2 * g.KP * g.DP + g.KP] = sum;
+        }
+    }
+}
+
+// totals[e] = sum over the G partial sets, fixed order: 64 elements per workgroup, 4 interleaved set ranges per element
+__global__ void __launch_bounds__(256) gmm_mstep_reduce_kernel(const double* __restrict__ part, long long set_stride, int G,
+                                                               long long E, double* __restrict__ totals) {
+    __shared__ double sh[4][64];
+    const int el = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + el;
+    double acc = 0.0;
+    if (e < E)
+        for (int s0 = pr; s0 < G; s0 += 32) {
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (s0 + 4 * i < G) ? part[(size_t)(s0 + 4 * i) * set_stride + e] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i];
+        }
+    sh[pr][el] = acc;
+    __syncthreads();
+    if (pr == 0 && e < E) totals[e] = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
+}
+
+// one workgroup per component: parameters from the totals
+__global__ void __launch_bounds__(128) gmm_mstep_params_kernel(const double* __restrict__ totals, int KP, int DP, int k, int d,
+                                                               long long N, double reg_covar, double* __restrict__ weights,
+                                                               double* __restrict__ means, double* __restrict__ covariances,
+                                                               double* __restrict__ precisions_chol, double* __restrict__ stats) {
+    const int c = blockIdx.x;
+    const double* nkp = totals + (size_t)2 * KP * DP;
+    const double eps10 = 10.0 * 2.220446049250313e-16;
+    double wsum = 0.0;
+    for (int i = 0; i < k; ++i) wsum += nkp[i] + eps10;
+    const double nk = nkp[c] + eps10;
+    int bad = 0;
+    for (int j = threadIdx.x; j < d; j += 128) {
+        const double m = totals[(size_t)c * DP + j] / nk;
+        const double cov = totals[((size_t)KP + c) * DP + j] / nk - m * m + reg_covar;
+        means[(size_t)c * d + j] = m;
+        covariances[(size_t)c * d + j] = cov;
+        precisions_chol[(size_t)c * d + j] = 1.0 / sqrt(cov);
+        bad |= !(cov > 0.0);
+    }
+    if (threadIdx.x == 0) weights[c] = nk / wsum;
+    if (c == 0 && threadIdx.x == 0) stats[0] = nkp[KP] / (double)N;       // lower bound: mean log_prob_norm
+    if (bad) stats[1] = 1.0;                                              // benign race: every writer stores the same value
+}
+
+template <int CT>
+void launch_mstep(const GmmMArgs& g, int G, int chunks, hipStream_t st) {
+    hipLaunchKernelGGL((gmm_mstep_kernel<CT>), dim3(G, chunks), dim3(256), 0, st, g);
+}
+
 }  // namespace
 
 extern "C" {
@@ -407,6 +586,56 @@ int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int 
         default: hipLaunchKernelGGL((gmm_estep_kernel<4>), dim3(grid), dim3(256), 0, st, g); break;
     }
     CLAVA_CHECK_LAUNCH("clava_gmm_estep_f64");
+    return CLAVA_OK;
+}
+
+long long clava_gmm_mstep_workspace_doubles(int k, int d) {
+    const long long KP = (k + 15) / 16 * 16, DP = (d + 31) / 32 * 32;
+    return (512 + 1) * (2 * KP * DP + KP + 1) + 2;
+}
+
+int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
+                        const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
+                        double* covariances, double* precisions_chol, double* stats, void* stream) {
+    CLAVA_CHECK_ARG(X && log_resp && workspace && weights && means && covariances && precisions_chol && stats,
+                    "gmm_mstep: null argument");
+    CLAVA_CHECK_ARG(N > 0 && d > 0 && k > 0 && ldx >= d, "gmm_mstep: bad shape N=%lld d=%d k=%d", N, d, k);
+    if (k > KMAX) {
+        clava_set_error("gmm_mstep: k=%d components exceeds the supported maximum of %d", k, KMAX);
+        return CLAVA_ERR_LIMIT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int CT = (k + 15) / 16, chunks = (d + 31) / 32;
+    GmmMArgs g;
+    g.X = X; g.ldx = ldx; g.N = N; g.d = d; g.k = k; g.log_resp = log_resp; g.log_prob_norm = log_prob_norm;
+    g.KP = CT * 16; g.DP = chunks * 32;
+    g.set_stride = 2LL * g.KP * g.DP + g.KP + 1;
+    g.part = workspace;
+    const long long groups = (N + 15) / 16;
+    long long G = (groups + 3) / 4;
+    if (G > 512) G = 512;
+    if (G < 1) G = 1;
+    double* totals = workspace + (size_t)512 * g.set_stride;
+    if (hipMemsetAsync(stats, 0, 2 * sizeof(double), st) != hipSuccess) {
+        clava_set_error("gmm_mstep: hipMemsetAsync failed");
+        return CLAVA_ERR_LAUNCH;
+    }
+    {
+        ProfScope prof(PROF_GMM, 4.0 * N * d * k, 8.0 * N * (d + (double)k * chunks + 1), st);
+        switch (CT) {
+            case 1: launch_mstep<1>(g, (int)G, chunks, st); break;
+            case 2: launch_mstep<2>(g, (int)G, chunks, st); break;
+            case 3: launch_mstep<3>(g, (int)G, chunks, st); break;
+            default: launch_mstep<4>(g, (int)G, chunks, st); break;
+        }
+        CLAVA_CHECK_LAUNCH("clava_gmm_mstep_f64");
+    }
+    const long long E = g.set_stride;
+    hipLaunchKernelGGL(gmm_mstep_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, g.part, g.set_stride, (int)G, E, totals);
+    CLAVA_CHECK_LAUNCH("clava_gmm_mstep_f64(reduce)");
+    hipLaunchKernelGGL(gmm_mstep_params_kernel, dim3(k), dim3(128), 0, st, totals, g.KP, g.DP, k, d, N, reg_covar, weights, means,
+                       covariances, precisions_chol, stats);
+    CLAVA_CHECK_LAUNCH("clava_gmm_mstep_f64(params)");
     return CLAVA_OK;
 }
 

@@ -353,6 +353,20 @@ int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int 
                         const double* means, const double* precisions_chol, double* workspace, double* log_prob_norm,
                         double* log_resp, int* labels, void* stream);
 
+/* M-step of the same mixture: scikit-learn's GaussianMixture._m_step for covariance_type='diag'
+ * (sklearn/mixture/_gaussian_mixture.py `_estimate_gaussian_parameters`, `_estimate_gaussian_covariances_diag`,
+ * `_compute_precision_cholesky`; called once per EM iteration from BaseMixture.fit_predict, _base.py) with
+ * resp = exp(log_resp[N,k]):  nk = sum_n resp + 10 eps;  means = resp^T X / nk;
+ * covariances = resp^T X^2 / nk - means^2 + reg_covar;  weights = nk / sum(nk);  precisions_chol = 1/sqrt(covariances).
+ * stats[0] receives mean_n log_prob_norm[n] (the EM lower bound of `_compute_lower_bound`; 0 when log_prob_norm is
+ * NULL) and stats[1] is set to 1 when a covariance is not positive (scikit-learn raises there).  weights[k],
+ * means / covariances / precisions_chol [k,d] and stats[2] are device arrays; workspace holds
+ * clava_gmm_mstep_workspace_doubles(k, d) doubles.  All sums have a fixed order.  Returns -3 when k exceeds 64. */
+long long clava_gmm_mstep_workspace_doubles(int k, int d);
+int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
+                        const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
+                        double* covariances, double* precisions_chol, double* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

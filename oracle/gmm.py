@@ -26,3 +26,40 @@ def estep(X, weights, means, precisions_chol):
     m = wlp.max(axis=1, keepdims=True)
     lpn = (m + np.log(np.exp(wlp - m).sum(axis=1, keepdims=True)))[:, 0]   # scipy logsumexp
     return lpn, wlp - lpn[:, None], wlp.argmax(axis=1)
+
+
+def mstep(X, log_resp, reg_covar=1e-6):
+    """scikit-learn's `GaussianMixture._m_step`, 'diag' branch (`sklearn/mixture/_gaussian_mixture.py`:
+    `_estimate_gaussian_parameters`, `_estimate_gaussian_covariances_diag`, `_compute_precision_cholesky`;
+    scikit-learn 1.7.2 as installed - the release the reference pins, 1.4.1.post1, computes the same covariance as
+    avg_X2 - 2 avg_X_means + avg_means2, equal in exact arithmetic).
+
+    Returns (weights [k], means [k,d], covariances [k,d], precisions_chol [k,d])."""
+    resp = np.exp(log_resp)
+    nk = resp.sum(axis=0) + 10 * np.finfo(resp.dtype).eps
+    means = np.dot(resp.T, X) / nk[:, None]
+    cov = np.dot(resp.T, X * X) / nk[:, None] - means ** 2 + reg_covar
+    weights = nk / nk.sum()
+    if np.any(cov <= 0.0):
+        raise ValueError("ill-defined empirical covariance")
+    return weights, means, cov, 1.0 / np.sqrt(cov)
+
+
+def em(X, weights, means, precisions_chol, tol=1e-4, max_iter=100, reg_covar=1e-6):
+    """The EM loop of `BaseMixture.fit_predict` (`sklearn/mixture/_base.py`) from given initial parameters, n_init = 1:
+    E-step, M-step, lower bound = mean log_prob_norm, stop when its change is below `tol`; then the final E-step.
+    Returns (weights, means, covariances, precisions_chol, n_iter, lower_bound, converged, labels)."""
+    lower = -np.inf
+    cov = None
+    converged = False
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        prev = lower
+        lpn, log_resp, _ = estep(X, weights, means, precisions_chol)
+        weights, means, cov, precisions_chol = mstep(X, log_resp, reg_covar)
+        lower = lpn.mean()
+        if abs(lower - prev) < tol:
+            converged = True
+            break
+    _, log_resp, _ = estep(X, weights, means, precisions_chol)
+    return weights, means, cov, precisions_chol, n_iter, lower, converged, log_resp.argmax(axis=1)

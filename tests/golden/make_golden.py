@@ -501,9 +501,41 @@ def g10_classifier_training():
     save("g10_classifier_training.npz", **out)
 
 
+# --------------------------------------------------------------------------- G11
+def g11_gmm_fit():
+    """scikit-learn's own M-step and EM loop (the GaussianMixture the reference builds at pipeline_modules.py:268-277):
+    one `_m_step` from the responsibilities of the G9 mixture, and a whole `fit_predict` from recorded k-means++
+    initial parameters (weights / means / precisions the M-step of `_initialize` produced)."""
+    from sklearn.mixture import GaussianMixture
+    from sklearn.mixture._gaussian_mixture import _compute_precision_cholesky, _estimate_gaussian_parameters
+    g9 = np.load(os.path.join(HERE, "g9_gmm.npz"))
+    X = g9["X"]
+    nk, means, cov = _estimate_gaussian_parameters(X, np.exp(g9["log_resp"]), 1e-6, "diag")
+    out = {"m_weights": nk / nk.sum(), "m_means": means, "m_cov": cov, "m_prec_chol": _compute_precision_cholesky(cov, "diag")}
+    rng = np.random.RandomState(11)
+    N, k = 4000, 9
+    centers = rng.uniform(-3, 3, (k, 7))
+    lab = rng.randint(0, k, N)
+    X2 = centers[lab] + rng.standard_normal((N, 7)) * rng.uniform(0.2, 0.9, (k, 7))[lab]
+    X2 = np.concatenate([X2, 2.0 * np.eye(3)[rng.randint(0, 3, N)], 0.01 * rng.uniform(0, 1, (N, 1))], axis=1)
+    init = GaussianMixture(n_components=k, covariance_type="diag", init_params="k-means++", tol=1e-4, random_state=3, max_iter=0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        init.fit(X2)
+    w0, m0, p0 = init.weights_.copy(), init.means_.copy(), init.precisions_cholesky_.copy()
+    # the run itself: same seed, hence the same k-means++ start (w0 sums to k/N: `_initialize` divides nk by n_samples)
+    gm = GaussianMixture(n_components=k, covariance_type="diag", init_params="k-means++", tol=1e-4, random_state=3)
+    labels = gm.fit_predict(X2)
+    out.update({"X": X2, "w0": w0, "m0": m0, "pc0": p0, "weights": gm.weights_, "means": gm.means_, "cov": gm.covariances_,
+                "prec_chol": gm.precisions_cholesky_, "n_iter": gm.n_iter_, "lower_bound": gm.lower_bound_,
+                "converged": int(gm.converged_), "labels": labels.astype(np.int64)})
+    save("g11_gmm_fit.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     fns = {"g1": g1_schedule, "g2": g2_mlp, "g3": g3_gauss_step, "g4": g4_multinomial_step, "g5": g5_chains,
-           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training}
+           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training, "g11": g11_gmm_fit}
     for w in which:
         fns[w]()

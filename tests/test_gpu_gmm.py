@@ -72,3 +72,81 @@ def test_row_sharded_estep_equals_the_single_call():
     parts = [parallel.gmm_estep_rows(X, w, means, pc, rank=r, world=3, gather=False) for r in range(3)]
     assert torch.equal(torch.cat([p[1] for p in parts]), lab.cpu().long())
     assert torch.equal(torch.cat([p[0] for p in parts]), lpn.cpu())        # rows are independent: bit-identical
+
+
+# ------------------------------------------------------------------------------------------------ M-step / EM loop
+def _mstep(X, log_resp, lpn=None, reg=1e-6, ldx=None):
+    from clavaddpm_amd.clustering import gmm_mstep, unpack_mstep
+    Xd = torch.from_numpy(X).to(DEV)
+    if ldx is not None:                      # rows embedded in a wider buffer
+        wide = torch.zeros((X.shape[0], ldx), device=DEV, dtype=torch.float64)
+        wide[:, :X.shape[1]] = Xd
+        Xd = wide[:, :X.shape[1]]
+    out = gmm_mstep(Xd, torch.from_numpy(log_resp).to(DEV), None if lpn is None else torch.from_numpy(lpn).to(DEV), reg)
+    return [t.cpu().numpy() for t in unpack_mstep(out, log_resp.shape[1], X.shape[1])]
+
+
+def test_g11_mstep_golden():
+    g, g9 = golden("g11_gmm_fit.npz"), golden("g9_gmm.npz")
+    st, w, m, cv, pc = _mstep(g9["X"].numpy(), g9["log_resp"].numpy(), g9["log_prob_norm"].numpy())
+    np.testing.assert_allclose(w, g["m_weights"].numpy(), rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(m, g["m_means"].numpy(), rtol=1e-10, atol=1e-12)
+    # covariances subtract means^2 from the second moment: absolute error scales with means^2 * 1e-16
+    np.testing.assert_allclose(cv, g["m_cov"].numpy(), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(pc, g["m_prec_chol"].numpy(), rtol=1e-8, atol=1e-12)
+    assert abs(st[0] - g9["log_prob_norm"].numpy().mean()) < 1e-12 and st[1] == 0.0
+
+
+@pytest.mark.parametrize("N,d,k,ldx", [(1, 1, 1, None), (17, 3, 2, None), (1000, 5, 3, 8), (777, 129, 64, None),
+                                       (50000, 40, 50, None), (4096, 32, 16, 40), (65, 33, 17, None)])
+def test_gmm_mstep_vs_oracle(N, d, k, ldx):
+    rng = np.random.RandomState(N + d + k)
+    X = rng.standard_normal((N, d)) * 2.0 + rng.uniform(-3, 3, (1, d))
+    logits = rng.standard_normal((N, k)) * 3.0
+    log_resp = logits - np.log(np.exp(logits).sum(1, keepdims=True))
+    log_resp[::7, 0] = -800.0                                  # responsibilities that underflow to zero
+    lpn = rng.standard_normal(N)
+    w_r, m_r, c_r, pc_r = ogmm.mstep(X, log_resp, reg_covar=1e-6)
+    st, w, m, cv, pc = _mstep(X, log_resp, lpn, 1e-6, ldx)
+    np.testing.assert_allclose(w, w_r, rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(m, m_r, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(cv, c_r, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(pc, pc_r, rtol=1e-8, atol=1e-10)
+    assert abs(st[0] - lpn.mean()) < 1e-12 and st[1] == 0.0
+    assert abs(w.sum() - 1.0) < 1e-14                          # size-independent property: weights are a distribution
+
+
+def test_gmm_mstep_is_bitwise_reproducible_and_flags_bad_covariances():
+    rng = np.random.RandomState(5)
+    X = rng.standard_normal((30000, 24))
+    lr = np.log(rng.dirichlet(np.ones(20), 30000))
+    a = _mstep(X, lr)
+    b = _mstep(X, lr)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    X[:, 3] = 1.5                                              # a constant column: zero variance without regularisation
+    assert _mstep(X, lr, reg=0.0)[0][1] == 1.0
+    from clavaddpm_amd.clustering import HipGaussianMixture
+    with pytest.raises(ValueError, match="ill-defined empirical covariance"):
+        HipGaussianMixture(n_components=3, covariance_type="diag", reg_covar=0.0, random_state=0).fit(X[:2000])
+
+
+def test_g11_device_em_loop_matches_sklearn_run():
+    """`fit` with E-step, M-step and lower bound on the device against scikit-learn's own run (recorded in G11): same
+    number of EM iterations, parameters to 1e-8, identical cluster labels."""
+    from clavaddpm_amd.clustering import HipGaussianMixture
+    g = golden("g11_gmm_fit.npz")
+    X = g["X"].numpy()
+    gm = HipGaussianMixture(n_components=g["means"].shape[0], covariance_type="diag", init_params="k-means++", tol=1e-4,
+                            random_state=3)
+    labels = gm.fit_predict(X)
+    assert gm.n_iter_ == int(g["n_iter"]) and gm.converged_ == bool(int(g["converged"]))
+    # 16 EM iterations of float64 sums in another order than BLAS (E-step agreement is ~1e-10 per call, see above)
+    assert abs(gm.lower_bound_ - float(g["lower_bound"])) < 1e-8
+    np.testing.assert_allclose(gm.weights_, g["weights"].numpy(), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(gm.means_, g["means"].numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(gm.covariances_, g["cov"].numpy(), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(gm.precisions_cholesky_, g["prec_chol"].numpy(), rtol=1e-7, atol=1e-10)
+    assert np.array_equal(labels, g["labels"].numpy()) and np.array_equal(gm.predict(X), g["labels"].numpy())
+    # the numpy-facing pieces still work after a device fit
+    lpn, lr = gm._estimate_log_prob_resp(X[:100])
+    assert lpn.shape == (100,) and lr.shape == (100, gm.n_components)

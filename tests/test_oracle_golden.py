@@ -205,5 +205,18 @@ def test_g10_classifier_training_trajectory():
     assert abs(vl - float(g["val_loss"][0])) < 1e-5 * abs(vl) and abs(va - float(g["val_acc1"][0])) < 1e-6
 
 
+def test_g11_gmm_mstep_and_em_loop():
+    g, g9 = golden("g11_gmm_fit.npz"), golden("g9_gmm.npz")
+    w, m, c, pc = gmm.mstep(g9["X"].numpy(), g9["log_resp"].numpy())
+    for got, key in ((w, "m_weights"), (m, "m_means"), (c, "m_cov"), (pc, "m_prec_chol")):
+        np.testing.assert_allclose(got, g[key].numpy(), rtol=1e-13, atol=1e-15)
+    r = gmm.em(g["X"].numpy(), g["w0"].numpy(), g["m0"].numpy(), g["pc0"].numpy())
+    assert r[4] == int(g["n_iter"]) and r[6] == bool(int(g["converged"]))
+    assert abs(r[5] - float(g["lower_bound"])) < 1e-12
+    for got, key in ((r[0], "weights"), (r[1], "means"), (r[2], "cov"), (r[3], "prec_chol")):
+        np.testing.assert_allclose(got, g[key].numpy(), rtol=1e-10, atol=1e-12)
+    assert np.array_equal(r[7], g["labels"].numpy())
+
+
 def test_oracle_header_says_test_only():
     assert "TEST INFRASTRUCTURE ONLY" in oracle.__doc__
