@@ -186,7 +186,7 @@ def gmm_bench(device, n_rows, d, k, iters, cpu_rows):
     is bound by the f64 matrix pipe (4*N*d*k algorithmic FLOP; v_mfma_f64_16x16x4_f64 sustains 45 TFLOP/s on this chip,
     tools/micro/mfma_f64_rate.hip, against 78.6 in AMD's data sheet); algorithmic bytes are 8*N*(d + k + 1)."""
     import numpy as np
-    from clavaddpm_amd.clustering import gmm_estep
+    from clavaddpm_amd.clustering import gmm_estep, gmm_mstep
     from oracle import gmm as ogmm
     rng = np.random.RandomState(0)
     means = rng.standard_normal((k, d))
@@ -205,13 +205,35 @@ def gmm_bench(device, n_rows, d, k, iters, cpu_rows):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
+    # M-step and one whole EM iteration (E-step, M-step, lower bound; N-sized data never leaves the device)
+    for _ in range(2):
+        gmm_mstep(X, resp, lpn)
+    c, e, f2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    c.record()
+    for _ in range(iters):
+        gmm_mstep(X, resp, lpn)
+    e.record()
+    for _ in range(iters):
+        lpn, resp, lab = gmm_estep(X, wd, md, pd_)
+        gmm_mstep(X, resp, lpn)
+    f2.record()
+    torch.cuda.synchronize()
+    ms_m, ms_em = c.elapsed_time(e) / iters, e.elapsed_time(f2) / iters
     bytes_alg = 8.0 * n_rows * (d + k + 1)
     Xc = X[:cpu_rows].cpu().numpy()
     t0 = time.perf_counter()
     lpn_c, resp_c, lab_c = ogmm.estep(Xc, w, means, pc)
     dt = time.perf_counter() - t0
     same = bool(np.array_equal(lab[:cpu_rows].cpu().numpy().astype(np.int64), lab_c))
+    t0 = time.perf_counter()
+    ogmm.mstep(Xc, resp_c)
+    dtm = time.perf_counter() - t0
     return {"rows": n_rows, "d": d, "k": k, "dtype": "f64", "ms_per_estep": round(ms, 3), "rows_per_s": round(n_rows / ms * 1e3, 0),
+            "mstep": {"ms": round(ms_m, 3), "tflops_f64": round(4.0 * n_rows * d * k / ms_m / 1e9, 2),
+                      "hbm_gbps": round(8.0 * n_rows * (d + k * ((d + 31) // 32) + 1) / ms_m / 1e6, 1),
+                      "cpu_rows_per_s": round(cpu_rows / dtm, 0)},
+            "em_iteration": {"ms": round(ms_em, 3), "rows_per_s": round(n_rows / ms_em * 1e3, 0),
+                             "cpu_rows_per_s": round(cpu_rows / (dt + dtm), 0)},
             "roofline": {"bound": "mfma", "achieved": round(4.0 * n_rows * d * k / ms / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
                          "frac": round(4.0 * n_rows * d * k / ms / 1e9 / 78.6, 4), "measured_f64_mfma_peak": 45.4,
                          "frac_of_measured_peak": round(4.0 * n_rows * d * k / ms / 1e9 / 45.4, 4),

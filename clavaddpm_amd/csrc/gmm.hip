@@ -372,7 +372,7 @@ struct GmmMArgs {
     long long set_stride;
 };
 
-template <int CT>
+template <int CT, int RS>   // 16-component tiles, K-slices (of four samples) per register-staged row group
 __global__ void __launch_bounds__(256) gmm_mstep_kernel(GmmMArgs g) {
     __shared__ double red[4][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,13 +393,14 @@ __global__ void __launch_bounds__(256) gmm_mstep_kernel(GmmMArgs g) {
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) jv[jt] = j0 + jt * 16 + c16 < g.d;
 
-    const long long groups = (g.N + 15) / 16;
+    constexpr int GR = 4 * RS;                      // rows per group
+    const long long groups = (g.N + GR - 1) / GR;
     const long long stride = (long long)gridDim.x * 4;
-    double la[4][CT], xb[4][2], lp[4];
+    double la[RS][CT], xb[RS][2], lp[RS];
     auto load = [&](long long gi) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long n = gi * 16 + q + 4 * r;
+        for (int r = 0; r < RS; ++r) {
+            const long long n = gi * GR + q + 4 * r;
             const bool ok = n < g.N;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -412,9 +413,9 @@ __global__ void __launch_bounds__(256) gmm_mstep_kernel(GmmMArgs g) {
     long long gi = (long long)blockIdx.x * 4 + wave;
     if (gi < groups) load(gi);
     for (; gi < groups; gi += stride) {
-        double a[4][CT], x[4][2];
+        double a[RS][CT], x[RS][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RS; ++r) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) a[r][ct] = la[r][ct] == -INFINITY ? 0.0 : exp_nonpos(la[r][ct]);
 #pragma unroll
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(256) gmm_mstep_kernel(GmmMArgs g) {
         }
         if (gi + stride < groups) load(gi + stride);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RS; ++r)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 nk[ct] += a[r][ct];
@@ -526,7 +527,8 @@ __global__ void __launch_bounds__(128) gmm_mstep_params_kernel(const double* __r
 
 template <int CT>
 void launch_mstep(const GmmMArgs& g, int G, int chunks, hipStream_t st) {
-    hipLaunchKernelGGL((gmm_mstep_kernel<CT>), dim3(G, chunks), dim3(256), 0, st, g);
+    // four tiles of components leave room for two K-slices of staged operands only (four spill)
+    hipLaunchKernelGGL((gmm_mstep_kernel<CT, (CT == 4 ? 2 : 4)>), dim3(G, chunks), dim3(256), 0, st, g);
 }
 
 }  // namespace
@@ -611,7 +613,7 @@ int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int 
     g.KP = CT * 16; g.DP = chunks * 32;
     g.set_stride = 2LL * g.KP * g.DP + g.KP + 1;
     g.part = workspace;
-    const long long groups = (N + 15) / 16;
+    const long long groups = (N + 15) / 16;          // at least: a wavefront walks whole row groups
     long long G = (groups + 3) / 4;
     if (G > 512) G = 512;
     if (G < 1) G = 1;
