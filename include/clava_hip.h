@@ -367,6 +367,18 @@ int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int 
                         const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
                         double* covariances, double* precisions_chol, double* stats, void* stream);
 
+/* ---- post-sampling decoding of numeric columns ------------------------------------------------------
+ * out[N,d] = QuantileTransformer(output_distribution='normal').inverse_transform(x[N,d]) in float64: the
+ * `dataset.num_transform.inverse_transform(...)` of pipeline_utils.py:913 (transformer built at lib/data.py:217-223;
+ * arithmetic: sklearn/preprocessing/_data.py `_transform_col`, inverse branch = scipy norm.cdf, np.interp over
+ * (references_, quantiles_[:, col]), the 1e-7 bound clamps).  quantiles is sklearn's quantiles_ [n_quantiles, d]
+ * row-major, references its references_ [n_quantiles]; out may alias x.  NaN in, NaN out. */
+int clava_quantile_inverse_f64(const double* x, long long ldx, long long N, int d, const double* quantiles, const double* references,
+                               int n_quantiles, double* out, long long ldo, void* stream);
+/* x[:, col] <- nearest of values[n_values] (sorted unique training values), distance sqrt((x-v)^2), first minimum wins:
+ * one column of lib.round_columns (lib/data.py:627-632; scipy cdist + argmin), in place. */
+int clava_round_to_values_f64(double* x, long long ldx, long long N, int col, const double* values, int n_values, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -533,9 +533,34 @@ def g11_gmm_fit():
     save("g11_gmm_fit.npz", **out)
 
 
+# --------------------------------------------------------------------------- G12
+def g12_postprocess():
+    """scikit-learn's `QuantileTransformer.inverse_transform` for the normaliser the reference fits (lib/data.py:217-223)
+    and the reference's own `round_columns` (lib/data.py:627-632, compiled from its source)."""
+    from scipy.spatial.distance import cdist
+    from sklearn.preprocessing import QuantileTransformer
+    round_columns = _compile(_extract("lib/data.py", "round_columns"), {"np": np, "cdist": cdist}, "lib/data.py")
+    rng = np.random.RandomState(12)
+    N = 6000
+    real = np.stack([rng.lognormal(0, 1, N), rng.randint(0, 7, N).astype(float), rng.standard_normal(N) * 50 + 10,
+                     np.round(rng.exponential(3, N)), rng.choice([1.0, 2.0, 4.0, 8.0], N)], axis=1)
+    qt = QuantileTransformer(output_distribution="normal", n_quantiles=max(min(N // 30, 1000), 10), subsample=int(1e9),
+                             random_state=0).fit(real)
+    x = rng.standard_normal((3000, 5)) * 1.3
+    x[:40] = rng.standard_normal((40, 5)) * 6                 # far tails: the 1e-7 clamps
+    x[40, :] = [0.0, -0.0, 5.1993375821928165, -5.1993375821928165, 8.3]
+    x[41, 2] = np.nan
+    x[42, :] = qt.transform(real[:1])[0]                       # lands on a quantile knot
+    inv = qt.inverse_transform(x.copy())
+    cols = [1, 3, 4]
+    rounded = round_columns(real, inv.copy(), cols)
+    save("g12_postprocess.npz", quantiles=qt.quantiles_, references=qt.references_, x=x, inverse=inv, real=real,
+         cols=np.array(cols), rounded=rounded)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = {"g1": g1_schedule, "g2": g2_mlp, "g3": g3_gauss_step, "g4": g4_multinomial_step, "g5": g5_chains,
-           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training, "g11": g11_gmm_fit}
+           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training, "g11": g11_gmm_fit, "g12": g12_postprocess}
     for w in which:
         fns[w]()

@@ -218,5 +218,15 @@ def test_g11_gmm_mstep_and_em_loop():
     assert np.array_equal(r[7], g["labels"].numpy())
 
 
+def test_g12_quantile_inverse_and_round_columns():
+    from oracle import postprocess
+    g = golden("g12_postprocess.npz")
+    inv = postprocess.quantile_inverse(g["x"].numpy(), g["quantiles"].numpy(), g["references"].numpy())
+    np.testing.assert_array_equal(inv, g["inverse"].numpy())                  # same numpy / scipy calls: bitwise (NaN == NaN)
+    r = postprocess.round_columns(g["real"].numpy(), g["inverse"].numpy(), g["cols"].tolist())
+    ok = ~np.isnan(g["rounded"].numpy())
+    assert np.array_equal(r[ok], g["rounded"].numpy()[ok]) and np.array_equal(np.isnan(r), ~ok)
+
+
 def test_oracle_header_says_test_only():
     assert "TEST INFRASTRUCTURE ONLY" in oracle.__doc__
