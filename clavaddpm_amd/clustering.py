@@ -77,6 +77,52 @@ def unpack_mstep(buf, k, d):
     return st, w, m, cv, pc
 
 
+def kmeans_plusplus(X, n_clusters, random_state):
+    """Indices of the k-means++ seeds of scikit-learn's `kmeans_plusplus(X, n_clusters, random_state=...)`
+    (`sklearn/cluster/_kmeans.py:_kmeans_plusplus`, unit sample weights) for a float64 device tensor X [N, d].
+    `random_state` is a `numpy.random.RandomState`; it is consumed exactly as scikit-learn consumes it (one `choice`,
+    then `uniform(size=2+int(log k))` per further centre), so a seeded run selects the same rows.  Distances, minima,
+    potentials, the cumulative distribution and the searches run on the device; one small readback per centre."""
+    _lib.require_cuda(X)
+    if X.dtype != torch.float64:
+        raise _lib.ClavaHipError("kmeans_plusplus: float64 tensor expected")
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    N, d = X.shape
+    if N < n_clusters:
+        raise ValueError(f"n_samples={N} should be >= n_clusters={n_clusters}.")
+    dev = X.device
+    T = 2 + int(np.log(n_clusters))
+    L = lib()
+    L.clava_kmpp_workspace_doubles.restype = ctypes.c_longlong
+    ws = torch.empty(int(L.clava_kmpp_workspace_doubles()), device=dev, dtype=torch.float64)
+    xsq = torch.empty(N, device=dev, dtype=torch.float64)
+    check(L.clava_kmpp_row_norms_f64(ptr(X), c_ll(X.stride(0)), c_ll(N), c_int(d), ptr(xsq), stream_ptr()), "clava_kmpp_row_norms_f64")
+    bufs = [torch.empty((T, N), device=dev, dtype=torch.float64) for _ in range(2)]
+    small = torch.empty(2 * T + 1, device=dev, dtype=torch.float64)          # potentials [T], ids as int64 bits [T], total
+    pots, ids, total = small[:T], small[T:2 * T].view(torch.int64), small[2 * T:]
+    sw = np.ones(N, dtype=np.float64)
+    center_id = int(random_state.choice(N, p=sw / sw.sum()))
+    indices = np.full(n_clusters, -1, dtype=int)
+    indices[0] = center_id
+    ids[0] = center_id
+    check(L.clava_kmpp_candidates_f64(ptr(X), c_ll(X.stride(0)), c_ll(N), c_int(d), ptr(xsq), None, ptr(ids), c_int(1), ptr(ws),
+                                      ptr(bufs[0]), ptr(pots), stream_ptr()), "clava_kmpp_candidates_f64")
+    closest, cur = bufs[0][0], 0
+    for c in range(1, n_clusters):
+        rand = torch.from_numpy(random_state.uniform(size=T)).to(dev)
+        check(L.clava_kmpp_pick_f64(ptr(closest), c_ll(N), ptr(rand), c_int(T), ptr(ws), ptr(ids), ptr(total), stream_ptr()),
+              "clava_kmpp_pick_f64")
+        nxt = bufs[1 - cur]
+        check(L.clava_kmpp_candidates_f64(ptr(X), c_ll(X.stride(0)), c_ll(N), c_int(d), ptr(xsq), ptr(closest), ptr(ids), c_int(T),
+                                          ptr(ws), ptr(nxt), ptr(pots), stream_ptr()), "clava_kmpp_candidates_f64")
+        host = small.cpu()                                                   # the one synchronisation per centre
+        best = int(np.argmin(host[:T].numpy()))
+        indices[c] = int(host[T:2 * T].view(torch.int64)[best])
+        closest, cur = nxt[best], 1 - cur
+    return indices
+
+
 class _DeviceResponsibilities:
     """What `_e_step` hands to `_m_step` during `fit`: device-resident log_resp / log_prob_norm / labels.  `argmax` serves
     the last line of scikit-learn's `fit_predict` (`log_resp.argmax(axis=1)`)."""
@@ -121,6 +167,24 @@ class HipGaussianMixture(_sk_gaussian_mixture()):
             raise NotImplementedError("HipGaussianMixture implements covariance_type='diag' (what ClavaDDPM uses)")
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
         return f(self.weights_), f(self.means_), f(self.precisions_cholesky_)
+
+    def _initialize_parameters(self, X, random_state):
+        """`BaseMixture._initialize_parameters` for init_params='k-means++' with no user-supplied initial parameters:
+        the seeds come from the device k-means++, and the one-hot responsibilities scikit-learn would build (an N x k
+        matrix whose M-step reduces to reading k rows) are replaced by that read: nk = 1 + 10 eps, means = X[seed] / nk,
+        covariances = X[seed]^2 / nk - means^2 + reg_covar, weights = nk / N (`GaussianMixture._initialize`)."""
+        if (self.init_params != "k-means++" or self.covariance_type != "diag" or self.weights_init is not None
+                or self.means_init is not None or self.precisions_init is not None):
+            return super()._initialize_parameters(X, random_state)
+        idx = kmeans_plusplus(self._device_x(X), self.n_components, random_state)
+        rows = np.asarray(X, dtype=np.float64)[idx]
+        nk = np.ones(self.n_components) + 10 * np.finfo(np.float64).eps
+        means = rows / nk[:, None]
+        cov = (rows * rows) / nk[:, None] - means ** 2 + self.reg_covar
+        self.weights_ = nk / X.shape[0]
+        self.means_ = means
+        self.covariances_ = cov
+        self.precisions_cholesky_ = 1.0 / np.sqrt(cov)
 
     # ---- EM loop of BaseMixture.fit_predict: everything of size N stays on the device
     def _fresh_dev_params(self):

@@ -367,6 +367,25 @@ int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int 
                         const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
                         double* covariances, double* precisions_chol, double* stats, void* stream);
 
+/* ---- k-means++ seeding on the device ------------------------------------------------------------------
+ * The N-sized arithmetic of scikit-learn's `_kmeans_plusplus` (sklearn/cluster/_kmeans.py), which seeds
+ * GaussianMixture(init_params='k-means++') (pipeline_modules.py:269-277); the random draws stay with the caller.
+ *   clava_kmpp_row_norms_f64    xsq[n] = sum_j X[n,j]^2                              (row_norms(X, squared=True))
+ *   clava_kmpp_candidates_f64   for the T <= 16 candidate rows candidates[t] (device int64):
+ *                               new_closest[t][n] = min(closest[n], max(0, -2 X[n].X[c] + xsq[c] + xsq[n])),
+ *                               potentials[t] = sum_n new_closest[t][n]; closest == NULL: no minimum (first centre)
+ *                               (`_euclidean_distances(..., squared=True)`, `np.minimum`, `@ sample_weight`)
+ *   clava_kmpp_pick_f64         ids[t] = searchsorted(cumsum(closest), rand01[t] * sum(closest)), clipped to N-1;
+ *                               *total = sum(closest)        (`stable_cumsum`, `np.searchsorted`, `np.clip`)
+ * workspace holds clava_kmpp_workspace_doubles() doubles; every sum has a fixed order.  -3 beyond 16 candidates. */
+long long clava_kmpp_workspace_doubles(void);
+int clava_kmpp_row_norms_f64(const double* X, long long ldx, long long N, int d, double* xsq, void* stream);
+int clava_kmpp_candidates_f64(const double* X, long long ldx, long long N, int d, const double* xsq, const double* closest,
+                              const long long* candidates, int T, double* workspace, double* new_closest, double* potentials,
+                              void* stream);
+int clava_kmpp_pick_f64(const double* closest, long long N, const double* rand01, int T, double* workspace, long long* ids,
+                        double* total, void* stream);
+
 /* ---- post-sampling decoding of numeric columns ------------------------------------------------------
  * out[N,d] = QuantileTransformer(output_distribution='normal').inverse_transform(x[N,d]) in float64: the
  * `dataset.num_transform.inverse_transform(...)` of pipeline_utils.py:913 (transformer built at lib/data.py:217-223;

@@ -150,3 +150,74 @@ def test_g11_device_em_loop_matches_sklearn_run():
     # the numpy-facing pieces still work after a device fit
     lpn, lr = gm._estimate_log_prob_resp(X[:100])
     assert lpn.shape == (100,) and lr.shape == (100, gm.n_components)
+
+
+# ------------------------------------------------------------------------------------------------ k-means++ seeding
+@pytest.mark.parametrize("N,d,k,seed", [(600, 10, 6, 0), (4000, 11, 9, 3), (50000, 32, 50, 7), (257, 1, 2, 1), (3000, 70, 25, 5)])
+def test_kmeans_plusplus_selects_sklearns_seeds(N, d, k, seed):
+    """scikit-learn is the reference here (third-party, importable on the box): same RandomState in, same seed rows out."""
+    from sklearn.cluster import kmeans_plusplus as sk_kmpp
+    from clavaddpm_amd.clustering import kmeans_plusplus
+    rng = np.random.RandomState(100 + seed)
+    centers = rng.uniform(-5, 5, (k, d))
+    X = centers[rng.randint(0, k, N)] + rng.standard_normal((N, d)) * 0.7
+    _, ref = sk_kmpp(X, k, random_state=np.random.RandomState(seed))
+    rs = np.random.RandomState(seed)
+    got = kmeans_plusplus(torch.from_numpy(X).to(DEV), k, rs)
+    assert np.array_equal(got, ref)
+    # the generator was consumed exactly as scikit-learn consumes it
+    rs_ref = np.random.RandomState(seed)
+    sk_kmpp(X, k, random_state=rs_ref)
+    assert rs.uniform() == rs_ref.uniform()
+
+
+def test_kmpp_primitives_vs_numpy():
+    import ctypes
+    from clavaddpm_amd._lib import c_int, check, lib, ptr, stream_ptr
+    rng = np.random.RandomState(2)
+    N, d, T = 10007, 13, 5
+    X = rng.standard_normal((N, d)) * 3
+    Xd = torch.from_numpy(X).to(DEV)
+    L = lib()
+    L.clava_kmpp_workspace_doubles.restype = ctypes.c_longlong
+    ws = torch.empty(int(L.clava_kmpp_workspace_doubles()), device=DEV, dtype=torch.float64)
+    xsq = torch.empty(N, device=DEV, dtype=torch.float64)
+    check(L.clava_kmpp_row_norms_f64(ptr(Xd), ctypes.c_longlong(d), ctypes.c_longlong(N), c_int(d), ptr(xsq), stream_ptr()), "norms")
+    np.testing.assert_allclose(xsq.cpu().numpy(), (X * X).sum(1), rtol=1e-14)
+    cand = torch.tensor([5, 900, 10006, 0, 5], device=DEV, dtype=torch.int64)
+    closest = torch.from_numpy(rng.uniform(0, 30, N)).to(DEV)
+    newd = torch.empty((T, N), device=DEV, dtype=torch.float64)
+    pots = torch.empty(T, device=DEV, dtype=torch.float64)
+    check(L.clava_kmpp_candidates_f64(ptr(Xd), ctypes.c_longlong(d), ctypes.c_longlong(N), c_int(d), ptr(xsq), ptr(closest), ptr(cand),
+                                      c_int(T), ptr(ws), ptr(newd), ptr(pots), stream_ptr()), "candidates")
+    C = X[cand.cpu().numpy()]
+    dist = np.maximum(-2 * C @ X.T + (C * C).sum(1)[:, None] + (X * X).sum(1)[None, :], 0)
+    ref = np.minimum(closest.cpu().numpy()[None, :], dist)
+    np.testing.assert_allclose(newd.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(pots.cpu().numpy(), ref.sum(1), rtol=1e-13)
+    assert float(newd[0, 5]) == 0.0 or float(newd[0, 5]) < 1e-12          # a candidate is at distance 0 from itself
+    # cumulative-distribution search, incl. both ends
+    r = torch.tensor([0.0, 0.25, 0.5, 0.999999, 1.0], device=DEV, dtype=torch.float64)
+    ids = torch.empty(T, device=DEV, dtype=torch.int64)
+    total = torch.empty(1, device=DEV, dtype=torch.float64)
+    check(L.clava_kmpp_pick_f64(ptr(closest), ctypes.c_longlong(N), ptr(r), c_int(T), ptr(ws), ptr(ids), ptr(total), stream_ptr()), "pick")
+    cl = closest.cpu().numpy()
+    cum = np.cumsum(cl)
+    want = np.clip(np.searchsorted(cum, r.cpu().numpy() * cum[-1]), None, N - 1)
+    got = ids.cpu().numpy()
+    assert abs(float(total) - cum[-1]) < 1e-9 * cum[-1]
+    assert np.all(np.abs(got - want) <= 1) and np.array_equal(got[[0]], want[[0]])    # a rounding-level tie may move one slot
+
+
+def test_hip_gaussian_mixture_fit_is_device_seeded_and_matches_sklearn():
+    """End to end with the device k-means++ in front of the device EM loop: scikit-learn's whole `fit` (G11 recording)."""
+    from unittest import mock
+    from clavaddpm_amd import clustering
+    g = golden("g11_gmm_fit.npz")
+    X = g["X"].numpy()
+    with mock.patch("sklearn.mixture._base.kmeans_plusplus", side_effect=AssertionError("host k-means++ was used")):
+        gm = clustering.HipGaussianMixture(n_components=9, covariance_type="diag", init_params="k-means++", tol=1e-4,
+                                           random_state=3).fit(X)
+    assert gm.n_iter_ == int(g["n_iter"])
+    np.testing.assert_allclose(gm.means_, g["means"].numpy(), rtol=1e-8, atol=1e-10)
+    assert np.array_equal(gm.predict(X), g["labels"].numpy())
