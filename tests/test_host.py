@@ -161,3 +161,53 @@ def test_relations_are_assigned_to_ranks_deterministically():
     assert plan3 == parallel.assign_relations(list(rel), 3, dict(cost))
     one = parallel.assign_relations(rel, 1)
     assert one == {0: rel}                                         # original order kept inside a rank
+
+
+def test_classifier_training_host_logic():
+    """Host pieces of the classifier-training path that need no GPU: the uniform timestep sampler reproduces the
+    reference's NumPy draw, the flat layout leaves the never-called transformer out, and the new product modules fail
+    loudly without a GPU instead of computing on the CPU."""
+    import numpy as np
+    from clavaddpm_amd import _lib, training
+    from clavaddpm_amd.classifier_training import ClassifierTrainer
+    from clavaddpm_amd.pipeline_utils import Classifier
+    from clavaddpm_amd.tab_ddpm.resample import create_named_schedule_sampler
+
+    class D:
+        num_timesteps = 1000
+    s = create_named_schedule_sampler("uniform", D())
+    np.random.seed(5)
+    t, w = s.sample(16, "cpu")
+    np.random.seed(5)
+    ref = np.random.choice(1000, size=(16,), p=np.ones(1000) / 1000)
+    assert t.dtype == torch.int64 and np.array_equal(t.numpy(), ref) and bool((w == 1).all())
+    with pytest.raises(NotImplementedError):
+        create_named_schedule_sampler("loss-second-moment", D())
+
+    clf = Classifier(d_in=3, d_out=4, dim_t=128, hidden_sizes=[16, 8], keep_unused_transformer=True)
+    lay = training.FlatLayout(clf, skip_prefixes=("transformer_layer",))
+    assert not any(n.startswith("transformer_layer") for n in lay.names)
+    assert set(lay.names) == {n for n, _ in clf.named_parameters() if not n.startswith("transformer_layer")}
+    assert all(o % 4 == 0 for o in lay.offsets)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.ClavaHipError):
+            ClassifierTrainer(clf, D())
+        with pytest.raises(_lib.ClavaHipError):          # CPU tensors are refused before anything else
+            clf.train()(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long))
+
+
+def test_clustering_and_postprocess_host_logic():
+    import numpy as np
+    from clavaddpm_amd import _lib, clustering, postprocess
+    k, d = 3, 2
+    buf = np.arange(2 + k + 3 * k * d, dtype=np.float64)
+    st, w, m, cv, pc = clustering.unpack_mstep(buf, k, d)
+    assert st.tolist() == [0, 1] and w.tolist() == [2, 3, 4] and m.shape == (k, d) and m[0, 0] == 5 and pc[-1, -1] == buf[-1]
+    real = np.array([[1.0, 0.5, 3.0], [2.0, 0.25, 3.0], [2.0, 7.5, 40.0]])
+    assert postprocess.discrete_columns(real) == [0, 2]
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.ClavaHipError):
+            clustering.kmeans_plusplus(torch.zeros((4, 2), dtype=torch.float64), 2, np.random.RandomState(0))
+        with pytest.raises(_lib.ClavaHipError):
+            postprocess.quantile_inverse(torch.zeros((4, 2), dtype=torch.float64), torch.zeros((10, 2), dtype=torch.float64),
+                                         torch.zeros(10, dtype=torch.float64))
