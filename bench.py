@@ -146,7 +146,7 @@ def classifier_train_bench(device, n_num, n_clusters, T, batch, steps, warmup, c
     clf = Classifier(d_in=n_num, d_out=n_clusters, dim_t=128, hidden_sizes=list(CLASSIFIER_LAYERS)).to(device).train()
     diff = GaussianMultinomialDiffusion(np.array([0]), n_num, None, num_timesteps=T, scheduler="cosine",
                                         device=torch.device(device)).to(device)
-    tr = ClassifierTrainer(clf, diff, lr=1e-4)
+    tr = ClassifierTrainer(clf, diff, lr=1e-4, data_parallel=False)      # this leg runs on rank 0 only
     x = torch.randn(8 * batch, n_num)
     y = torch.randint(0, n_clusters, (8 * batch,))
     for i in range(warmup):
@@ -434,11 +434,11 @@ def main():
                "note": "diffusion.conditional_sample(...) incl. host<->device copies of labels and samples"}
 
     gmm = None
-    if rank == 0 and not args.no_gmm:
+    if rank == 0 and world == 1 and not args.no_gmm:              # single-GPU side leg: reported at N = 1 only
         gmm = gmm_bench(device, 1_000_000, 32, 50, 20, 200_000 if not args.no_cpu_baseline else 20_000)
 
     clf_train = None
-    if rank == 0 and args.clf_train_steps > 0:
+    if rank == 0 and world == 1 and args.clf_train_steps > 0:     # single-GPU side leg: reported at N = 1 only
         clf_train = classifier_train_bench(device, args.n_num, args.clusters, T, 4096, args.clf_train_steps, 10,
                                            0 if args.no_cpu_baseline else 3)
 

@@ -177,7 +177,8 @@ class ClassifierTrainer:
     reference's data loaders; `history` collects (step, train loss, acc@1, acc@5[, val loss, val acc@1]) rows every
     `log_interval` steps (the reference's logger means, `:816-817`) without synchronising in between."""
 
-    def __init__(self, classifier, diffusion, lr=0.0001, weight_decay=0.01, device=None, remove_first_col=False):
+    def __init__(self, classifier, diffusion, lr=0.0001, weight_decay=0.01, device=None, remove_first_col=False,
+                 data_parallel=True):
         self.classifier = classifier
         self.diffusion = diffusion
         self.lr, self.weight_decay = lr, weight_decay
@@ -207,7 +208,11 @@ class ClassifierTrainer:
         self._keep = None
         self.world = 1
         self.dist = None
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # data parallel (every rank must construct the trainer and call step()): parameters broadcast once, one all-reduce
+        # of the flat gradient per step.  data_parallel=False keeps a trainer local to its rank (per-relation sharding,
+        # parallel.assign_relations: each rank trains other classifiers).
+        if (data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1):
             self.dist = torch.distributed
             self.world = self.dist.get_world_size()
             self.dist.broadcast(self.flat, src=0)
