@@ -266,6 +266,12 @@ def gmm_bench(device, n_rows, d, k, iters, cpu_rows):
                              "sample": f"{cpu_rows} rows, {dt:.2f} s", "labels_match_gpu": same}}
 
 
+def trace(msg):
+    """Progress markers on stderr (CLAVA_BENCH_TRACE=1): where a multi-rank run stands."""
+    if os.environ.get("CLAVA_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,11 +295,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # CLAVA_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives over gloo); measurements always use RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("CLAVA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         dist = None
     if not torch.cuda.is_available():
@@ -305,7 +319,12 @@ def main():
     L = _lib.lib()
     T, B = args.timesteps, args.batch
     split_nets.set_gemm_mode(args.gemm)
+    if os.environ.get("CLAVA_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("CLAVA_BENCH_TRACE_AFTER", "60")), exit=True)   # where a hung rank stands
+    trace("process group up; building the workload")
     diff, net, clf, cond_fn = build_workload(device, args.n_num, args.clusters, T, args.fit_steps)
+    trace("workload built")
     g = torch.Generator().manual_seed(1234 + rank)
     ys = torch.randint(0, args.clusters, (B, 1), generator=g).to(device)
 
@@ -323,12 +342,14 @@ def main():
     n_fam = L.clava_prof_family_count()
     L.clava_prof_family_name.restype = ctypes.c_char_p
 
+    trace("warm-up done")
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         x, keep = run_chain(diff, cond_fn, ys, seed + 1 + k, (world * k + rank) * B)
     barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     if dist is not None:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -397,6 +418,7 @@ def main():
                             "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
                             "flops_per_launch": round(fl[fi] / launches[fi])}
 
+    trace("roofline replay done")
     train = None
     if args.train_steps > 0:
         train = train_bench(device, args.n_num, T, 4096, args.train_steps, 10, barrier)
@@ -406,6 +428,7 @@ def main():
             train["ms_per_step"] = round(float(tm.item()), 3)
             train["steps_per_s"] = round(1e3 / float(tm.item()), 2)
 
+    trace("training leg done")
     # the same chain on the float32-input MFMA kernels (one chain, after the timed region): the exact-f32 reference point
     f32_leg = None
     if args.gemm == "f16x3" and not args.no_f32_leg:
@@ -476,6 +499,9 @@ def main():
         out["speedup_vs_cpu"] = round(value / v, 1)
     if rank == 0:
         print(json.dumps(out))
+    trace("done")
+    if os.environ.get("CLAVA_BENCH_TRACE"):
+        faulthandler.cancel_dump_traceback_later()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
+from . import parallel as _par
 from . import training as _tr
 from ._lib import ACT_LEAKY, ACT_RELU, c_float, c_int, check, lib, ptr, stream_ptr
 from .tab_ddpm.modules import timestep_embedding
@@ -215,7 +216,7 @@ class ClassifierTrainer:
                 and torch.distributed.get_world_size() > 1):
             self.dist = torch.distributed
             self.world = self.dist.get_world_size()
-            self.dist.broadcast(self.flat, src=0)
+            _par.broadcast_(self.flat, src=0)
             self.grad_flat = torch.zeros(total, device=dev, dtype=torch.float32)
 
     def _flatten(self):
@@ -327,7 +328,7 @@ class ClassifierTrainer:
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
-            self.dist.all_reduce(self.grad_flat)
+            _par.allreduce_sum_(self.grad_flat)
             g, S = self.grad_flat, 1
         else:
             g, S = self.slabs, _tr.GRAD_SPLITS

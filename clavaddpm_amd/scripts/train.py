@@ -13,12 +13,14 @@ What differs by design:
   * data parallelism (new): when torch.distributed is initialised, the flat gradient is averaged
     with one RCCL all-reduce per step; parameters are broadcast from rank 0 at construction.
 """
+import os
 from copy import deepcopy
 
 import numpy as np
 import pandas as pd
 import torch
 
+from .. import parallel as _par
 from .. import training as _tr
 from .._lib import c_float, c_int, check, lib, ptr, stream_ptr
 from ..training import c_ll
@@ -57,7 +59,7 @@ class Trainer:
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             self.dist = torch.distributed
             self.world = self.dist.get_world_size()
-            self.dist.broadcast(self.flat, src=0)
+            _par.broadcast_(self.flat, src=0)
         self.ema_model = deepcopy(net)
         self.ema_flat = self.flat.clone()
         for name, p in self.ema_model.named_parameters():
@@ -110,7 +112,11 @@ class Trainer:
                 p.data = v
         x = x.to(self.device)
         st = self._split_state()
-        if (st is not None and not st.due() and draws is None and not d.has_cat and self._use_graph):
+        # graph replay next to a process group: capture with RCCL's watchdog thread alive is supported by PyTorch, but it has
+        # not been exercised on a multi-GPU MI355X node yet; until then data-parallel runs stay eager unless
+        # CLAVA_TRAIN_GRAPH_DP=1 (the collective is outside the captured region either way)
+        use_graph = self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP") == "1")
+        if (st is not None and not st.due() and draws is None and not d.has_cat and use_graph):
             done = self._graphed_split_step(x, st)
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
@@ -162,7 +168,7 @@ class Trainer:
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
-            self.dist.all_reduce(self.grad_flat)             # RCCL sum over ranks of the pre-scaled flat gradient
+            _par.allreduce_sum_(self.grad_flat)              # RCCL sum over ranks of the pre-scaled flat gradient
             g, S, stride = self.grad_flat, 1, self.layout.total
         else:
             g, S, stride = self.slabs, _tr.GRAD_SPLITS, self.layout.total
