@@ -253,6 +253,11 @@ class ClassifierTrainer:
         if self.remove_first_col:
             x = x[:, 1:]
         x_num = x[:, :n].float().contiguous()
+        if not labels.is_cuda and labels.numel():          # the loaders yield CPU labels: check them where it costs nothing
+            lo, hi = int(labels.min()), int(labels.max())
+            n_out = _blocks(self.classifier)[2].out_features
+            if lo < 0 or hi >= n_out:
+                raise _lib.ClavaHipError(f"labels must lie in [0, {n_out}): got [{lo}, {hi}]")
         labels = labels.to(dev).long().contiguous()
         return x_num, labels
 

@@ -266,3 +266,6 @@ def test_run_loop_learns_separable_clusters(graph, monkeypatch):
     assert clf.proj.weight.data_ptr() != tr.flat.data_ptr()
     logits = clf(torch.randn(8, d_in, device=DEV), torch.zeros(8, dtype=torch.long, device=DEV))
     assert logits.shape == (8, C) and bool(torch.isfinite(logits).all())
+    clf.train()
+    with pytest.raises(_lib.ClavaHipError, match="labels must lie"):
+        tr.step(torch.randn(B, d_in), torch.full((B,), C, dtype=torch.long))

@@ -13,6 +13,7 @@ for mode in ("f32", "f16x3"):
     net = MLPDiffusion(2, 0, "none", {"d_layers": [512, 1024, 1024, 1024, 1024, 512], "dropout": 0.0}).to(dev).train()
     diff = GaussianMultinomialDiffusion(np.array([0]), 2, net, num_timesteps=1000, device=torch.device(dev)).to(dev).train()
     data = torch.randn(4096, 2); y = torch.zeros(4096, dtype=torch.long)
+    if os.environ.get("X_CUDA") == "1": data = data.cuda()
     tr = Trainer(diff, None, lr=6e-4, weight_decay=1e-5, steps=10**9, device=torch.device(dev))
     for _ in range(5): tr._run_step(data, {"y": y})
     torch.cuda.synchronize()
