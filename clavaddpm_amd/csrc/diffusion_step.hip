@@ -16,6 +16,7 @@
 // -ffp-contract=off so that a*b + c*d rounds like the separate ATen ops do.
 #include "rng.h"
 #include "step.h"
+#include "wave.h"
 
 namespace {
 
@@ -62,148 +63,213 @@ __global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ multinomial
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// log_add_exp (tab_ddpm/utils.py:104-106): one of the two exponentials is exp(0) = 1 exactly
-__device__ __forceinline__ float log_add_exp(float x, float y) {
-    const float m = fmaxf(x, y);
-    return m + logf(1.0f + expf(-fabsf(x - y)));
-}
-
-constexpr int CACHE = 16;            // classes per lane held in registers: blocks up to 64 * 16 = 1024 classes
 constexpr int MAX_LDS_FEATURES = 1024;
 
-struct BlockCtx {
-    const float* lg;     // logits of this (row, feature) block (REVERSE)
-    int K, hot, t, mode;
-    float mx, lsum;      // log-softmax statistics of the logits
-    float lca_p, l1mca_p, la_t, l1ma_t, logk;
-};
-
-// un-normalised log posterior of class c (REVERSE), or the q_pred log-probability (QSAMPLE), or 0 (INIT)
-__device__ __forceinline__ float unnormed(const BlockCtx& b, int c) {
-    if (b.mode == MULTI_MODE_INIT) return 0.f;
-    const float lx = (c == b.hot) ? 0.f : LOG_TINY;
-    if (b.mode == MULTI_MODE_QSAMPLE) return log_add_exp(lx + b.lca_p, b.l1mca_p - b.logk);          // q_pred at t (:403-412)
-    const float lp = (b.lg[c] - b.mx) - b.lsum;                                                       // predict_start (:414-424)
-    const float ev = (b.t == 0) ? lp : log_add_exp(lp + b.lca_p, b.l1mca_p - b.logk);                 // q_pred at t-1 (:436-443)
-    return ev + log_add_exp(lx + b.la_t, b.l1ma_t - b.logk);                                          // + q_pred_one_timestep (:449)
-}
-
-__global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) {
-    __shared__ int s_off[MAX_LDS_FEATURES + 1];
-    __shared__ float s_logk[MAX_LDS_FEATURES];
-    const bool staged = a.m <= MAX_LDS_FEATURES;
-    if (staged) {
-        for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
-        for (int i = threadIdx.x; i < a.m; i += blockDim.x) s_logk[i] = a.log_k[i];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
+// One (row, feature) block per group of G lanes.  G = 64: one wavefront per block, classes lane-strided, the block's
+// size, offset and hot class in scalar registers.  G = 8 / 16 / 32 (picked when every K of the table fits): 8 / 4 / 2
+// blocks per wavefront, one class per lane.  Three streaming passes over the block's logits (maximum, softmax sum,
+// draw; the second and third hit L1/L2): HBM sees each logit once.
+//
+// The posterior's normaliser (sliced_logsumexp, utils.py:151-166) is a per-block constant that cannot move the arg-max;
+// it is only evaluated when the caller asks for log p(x_{t-1} | x_t).
+//
+// In-kernel noise: one Philox call yields the uniforms of FOUR classes of a lane (classes c, c+G, c+2G, c+3G), keyed by
+// (seed, global row * m + feature, step, stream, slot = 64 * (c / 256) + (c & 63)) for G = 64: a pure function of
+// (row, feature, class), whatever the grid or GPU count.
+template <int G, int MODE>
+__device__ __forceinline__ void multinomial_blocks(const MultiStepArgs& a, const int* s_off, const float* s_logk,
+                                                   const float* s_side, bool staged) {
+    constexpr int NW = (G == 64) ? 4 : 1;
+    const int lane = threadIdx.x & (G - 1);
     const long long n_pairs = (long long)a.B * a.m;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long pair = wave0; pair < n_pairs; pair += n_waves) {
-        const int row = (int)(pair / a.m), f = (int)(pair - (long long)row * a.m);
-        const int o = staged ? s_off[f] : a.offsets[f];
-        BlockCtx b;
-        b.K = (staged ? s_off[f + 1] : a.offsets[f + 1]) - o;
-        b.logk = staged ? s_logk[f] : a.log_k[f];
-        b.mode = a.mode;
-        b.t = a.t_rows ? (int)a.t_rows[row] : a.t;
-        b.hot = (a.mode == MULTI_MODE_INIT) ? -1 : a.idx_in[(size_t)row * a.m + f];
-        b.lg = a.logits ? a.logits + (size_t)row * a.ld_logits + o : nullptr;
-        b.mx = 0.f; b.lsum = 0.f;
-        const int tp = (a.mode == MULTI_MODE_QSAMPLE) ? b.t : max(b.t - 1, 0);
-        b.lca_p = a.s.log_cumprod_alpha[tp];
-        b.l1mca_p = a.s.log_1_min_cumprod_alpha[tp];
-        b.la_t = a.s.log_alpha[b.t];
-        b.l1ma_t = a.s.log_1_min_alpha[b.t];
-
-        if (a.mode == MULTI_MODE_REVERSE) {       // log-softmax statistics of the block's logits
-            float mx = -INFINITY;
-            for (int c = lane; c < b.K; c += 64) mx = fmaxf(mx, b.lg[c]);
-            mx = wave_max(mx);
-            float sm = 0.f;
-            for (int c = lane; c < b.K; c += 64) sm += expf(b.lg[c] - mx);
-            b.mx = mx;
-            b.lsum = logf(wave_sum(sm));
+    const long long group0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const long long n_groups = ((long long)gridDim.x * blockDim.x) / G;
+    if (group0 >= n_pairs) return;
+    // (row, feature) advance by n_groups pairs per iteration without a division in the loop
+    int row = (int)(group0 / a.m), f = (int)(group0 - (long long)row * a.m);
+    const int d_row = (int)(n_groups / a.m), d_f = (int)(n_groups - (long long)d_row * a.m);
+    const unsigned stream_id = (MODE == MULTI_MODE_INIT) ? clava_rng::STREAM_INIT_CAT : clava_rng::STREAM_CAT;
+    const bool side_staged = staged && !a.t_rows;
+    for (; row < a.B; row += d_row, f += d_f) {
+        if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
+        int o = staged ? s_off[f] : a.offsets[f];
+        int K = (staged ? s_off[f + 1] : a.offsets[f + 1]) - o;
+        int hot = (MODE == MULTI_MODE_INIT) ? -1 : a.idx_in[(size_t)row * a.m + f];
+        if (G == 64) {
+            o = __builtin_amdgcn_readfirstlane(o);
+            K = __builtin_amdgcn_readfirstlane(K);
+            hot = __builtin_amdgcn_readfirstlane(hot);
         }
-
-        const bool cached = b.K <= 64 * CACHE;
-        float un[CACHE];
-        float lse = 0.f;
-        if (a.mode == MULTI_MODE_REVERSE) {       // normaliser of the posterior (sliced_logsumexp, utils.py:151-166)
-            float mx = -INFINITY;
-            if (cached) {
-#pragma unroll
-                for (int j = 0; j < CACHE; ++j) {
-                    const int c = lane + 64 * j;
-                    un[j] = (c < b.K) ? unnormed(b, c) : -INFINITY;
-                    mx = fmaxf(mx, un[j]);
-                }
+        const int t = a.t_rows ? (int)a.t_rows[row] : a.t;
+        const float* lg = (MODE == MULTI_MODE_REVERSE) ? a.logits + (size_t)row * a.ld_logits + o : nullptr;
+        float lca_p = 0.f, uni_p = 0.f, side_hot = 0.f, side_cold = 0.f;
+        if (MODE != MULTI_MODE_INIT) {
+            // the x_t-side factor takes two values per block: q_pred_one_timestep of the hot / any other class
+            // (:391-401); in QSAMPLE mode the whole log-probability does (q_pred at t, :403-412)
+            const float logk = staged ? s_logk[f] : a.log_k[f];
+            const int tp = (MODE == MULTI_MODE_QSAMPLE) ? t : max(t - 1, 0);
+            lca_p = a.s.log_cumprod_alpha[tp];
+            uni_p = a.s.log_1_min_cumprod_alpha[tp] - logk;
+            if (side_staged) {
+                side_hot = s_side[2 * f];
+                side_cold = s_side[2 * f + 1];
             } else {
-                for (int c = lane; c < b.K; c += 64) mx = fmaxf(mx, unnormed(b, c));
+                const float la = (MODE == MULTI_MODE_QSAMPLE) ? lca_p : a.s.log_alpha[t];
+                const float un = (MODE == MULTI_MODE_QSAMPLE) ? uni_p : a.s.log_1_min_alpha[t] - logk;
+                side_hot = log_add_exp(0.f + la, un);
+                side_cold = log_add_exp(LOG_TINY + la, un);
             }
-            mx = wave_max(mx);
-            float sm = 0.f;
-            if (cached) {
-#pragma unroll
-                for (int j = 0; j < CACHE; ++j) sm += (lane + 64 * j < b.K) ? expf(un[j] - mx) : 0.f;
-            } else {
-                for (int c = lane; c < b.K; c += 64) sm += expf(unnormed(b, c) - mx);
-            }
-            lse = mx + logf(wave_sum(sm));
         }
+        const unsigned long long pair_id = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.m + f;
 
+        float mx = 0.f, lsum = 0.f, lse = 0.f;
+        // un-normalised log posterior of class c with logit v (REVERSE), the q_pred log-probability (QSAMPLE), or 0 (INIT)
+        auto unnormed = [&](float v, int c) {
+            if (MODE == MULTI_MODE_INIT) return 0.f;
+            const float side = (c == hot) ? side_hot : side_cold;
+            if (MODE == MULTI_MODE_QSAMPLE) return side;
+            const float lp = (v - mx) - lsum;                                      // predict_start (:414-424)
+            float ev = lp;
+            if (t != 0) ev = log_add_exp(lp + lca_p, uni_p);                        // q_pred at t-1 (:436-443)
+            return ev + side;                                                      // + q_pred_one_timestep (:449)
+        };
         // Gumbel arg-max (log_sample_categorical, :506-516); ties resolve to the lowest class like torch.argmax
         float best = -INFINITY;
         int best_c = 0x7fffffff;
-        const unsigned long long elem0 = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.sumK + o;
-        auto visit = [&](int c, float u_n) {
-            const float lp = u_n - lse;
+        auto visit = [&](float v, int c, unsigned word) {
+            const float lp = unnormed(v, c) - lse;
             if (a.log_prob) a.log_prob[(size_t)row * a.ld_lp + o + c] = lp;
-            float u;
-            if (a.uniforms) {
-                u = a.uniforms[(size_t)row * a.ld_u + o + c];
-            } else {
-                const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem0 + c, a.step_index,
-                                                                 a.mode == MULTI_MODE_INIT ? clava_rng::STREAM_INIT_CAT : clava_rng::STREAM_CAT);
-                u = clava_rng::to_uniform(r.x);
-            }
-            const float g = -logf(-logf(u + 1e-30f) + 1e-30f);
+            const float u = a.uniforms ? a.uniforms[(size_t)row * a.ld_u + o + c] : clava_rng::to_uniform(word);
+            const float g = -log_pos(-log_pos(u + 1e-30f) + 1e-30f);
             const float sc = g + lp;
             if (sc > best) { best = sc; best_c = c; }
         };
-        if (cached && a.mode == MULTI_MODE_REVERSE) {
+        auto draws = [&](int c0) {
+            if (a.uniforms) return clava_rng::u4{0u, 0u, 0u, 0u};
+            return clava_rng::philox4x32_10(a.seed, pair_id, a.step_index, stream_id | ((unsigned)((c0 >> 8) * 64 + (c0 & 63)) << 3));
+        };
+        // NW classes per lane at a time: their loads are issued together, and a block of up to NW * G classes (256 for a
+        // wavefront) stays in registers through all passes
+        auto load4 = [&](int c0, float (&v)[NW]) {
 #pragma unroll
-            for (int j = 0; j < CACHE; ++j) {
-                const int c = lane + 64 * j;
-                if (c < b.K) visit(c, un[j]);
+            for (int w = 0; w < NW; ++w) {
+                const int c = c0 + w * G;
+                v[w] = (MODE == MULTI_MODE_REVERSE && c < K) ? lg[c] : -INFINITY;
             }
-        } else {
-            for (int c = lane; c < b.K; c += 64) visit(c, unnormed(b, c));
-        }
+        };
+        auto draw4 = [&](int c0, const float (&v)[NW]) {
+            const clava_rng::u4 r = draws(c0);
+            const unsigned words[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ob = __shfl_xor(best, off, 64);
-            const int oc = __shfl_xor(best_c, off, 64);
-            if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+            for (int w = 0; w < NW; ++w) {
+                const int c = c0 + w * G;
+                if (w == 0 || w * G < K) {          // wave-uniform for G = 64
+                    if (c < K) visit(v[w], c, words[w]);
+                }
+            }
+        };
+        if (K <= NW * G) {
+            float v[NW];
+            load4(lane, v);
+            if (MODE == MULTI_MODE_REVERSE) {
+                float m1 = v[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) m1 = fmaxf(m1, v[w]);
+                mx = group_max<G>(m1);
+                float sm = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    if (w == 0 || w * G < K) sm += exp_nonpos(v[w] - mx);      // exp(-inf) = 0 for the lanes beyond K
+                lsum = log_pos(group_sum<G>(sm));
+                if (a.log_prob) {
+                    float un[NW], m2 = -INFINITY;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const int c = lane + w * G;
+                        un[w] = (c < K) ? unnormed(v[w], c) : -INFINITY;
+                        m2 = fmaxf(m2, un[w]);
+                    }
+                    m2 = group_max<G>(m2);
+                    float sm2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sm2 += exp_nonpos(un[w] - m2);
+                    lse = m2 + log_pos(group_sum<G>(sm2));
+                }
+            }
+            draw4(lane, v);
+        } else {
+            float v[NW];
+            if (MODE == MULTI_MODE_REVERSE) {
+                float m1 = -INFINITY;
+                for (int c0 = lane; c0 < K; c0 += NW * G) {
+                    load4(c0, v);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) m1 = fmaxf(m1, v[w]);
+                }
+                mx = group_max<G>(m1);
+                float sm = 0.f;
+                for (int c0 = lane; c0 < K; c0 += NW * G) {
+                    load4(c0, v);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sm += exp_nonpos(v[w] - mx);
+                }
+                lsum = log_pos(group_sum<G>(sm));
+                if (a.log_prob) {
+                    float m2 = -INFINITY;
+                    for (int c = lane; c < K; c += G) m2 = fmaxf(m2, unnormed(lg[c], c));
+                    m2 = group_max<G>(m2);
+                    float sm2 = 0.f;
+                    for (int c = lane; c < K; c += G) sm2 += exp_nonpos(unnormed(lg[c], c) - m2);
+                    lse = m2 + log_pos(group_sum<G>(sm2));
+                }
+            }
+            for (int c0 = lane; c0 < K; c0 += NW * G) {
+                load4(c0, v);
+                draw4(c0, v);
+            }
         }
+        const float top = group_max<G>(best);
+        best_c = group_min<G>(best == top ? best_c : 0x7fffffff);
         if (lane == 0) a.idx_out[(size_t)row * a.m + f] = best_c;
         if (a.x_in) {                              // index_to_log_onehot for the next denoiser input (utils.py:127-134)
             float* xo = a.x_in + (size_t)row * a.ld_xin + o;
-            for (int c = lane; c < b.K; c += 64) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
+            for (int c = lane; c < K; c += G) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
         }
     }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) {
+    __shared__ int s_off[MAX_LDS_FEATURES + 1];
+    __shared__ float s_logk[MAX_LDS_FEATURES];
+    __shared__ float s_side[2 * MAX_LDS_FEATURES];
+    __shared__ int s_maxk;
+    const bool staged = a.m <= MAX_LDS_FEATURES;
+    if (threadIdx.x == 0) s_maxk = staged ? 0 : 64;
+    __syncthreads();
+    if (staged) {
+        int mk = 0;
+        for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
+        for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+            const float logk = a.log_k[i];
+            s_logk[i] = logk;
+            mk = max(mk, a.offsets[i + 1] - a.offsets[i]);
+            if (MODE != MULTI_MODE_INIT && !a.t_rows) {     // one t for the whole launch: the side factors depend on the feature only
+                const int tp = (MODE == MULTI_MODE_QSAMPLE) ? a.t : max(a.t - 1, 0);
+                const float la = (MODE == MULTI_MODE_QSAMPLE) ? a.s.log_cumprod_alpha[tp] : a.s.log_alpha[a.t];
+                const float un = ((MODE == MULTI_MODE_QSAMPLE) ? a.s.log_1_min_cumprod_alpha[tp] : a.s.log_1_min_alpha[a.t]) - logk;
+                s_side[2 * i] = log_add_exp(0.f + la, un);
+                s_side[2 * i + 1] = log_add_exp(LOG_TINY + la, un);
+            }
+        }
+        atomicMax(&s_maxk, mk);
+    }
+    __syncthreads();
+    const int maxk = s_maxk;                       // the same in every workgroup: all of them see the same table
+    if (maxk <= 8) multinomial_blocks<8, MODE>(a, s_off, s_logk, s_side, staged);
+    else if (maxk <= 16) multinomial_blocks<16, MODE>(a, s_off, s_logk, s_side, staged);
+    else if (maxk <= 32) multinomial_blocks<32, MODE>(a, s_off, s_logk, s_side, staged);
+    else multinomial_blocks<64, MODE>(a, s_off, s_logk, s_side, staged);
 }
 
 // forward noising of the numeric columns, per-row t (gaussian_q_sample, :172-180)
@@ -287,7 +353,9 @@ int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
     const int grid = (int)(blocks < 8192 ? blocks : 8192);
     // algorithmic bytes: logits 4/class in, log-one-hot 4/class out (+ injected uniforms 4/class), indices 4+4 per feature
     ProfScope prof(PROF_MULTI_STEP, 0.0, (double)a.B * ((double)a.sumK * ((a.logits ? 4 : 0) + (a.x_in ? 4 : 0) + (a.uniforms ? 4 : 0)) + 8.0 * a.m), stream);
-    hipLaunchKernelGGL(multinomial_step_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (a.mode == MULTI_MODE_REVERSE) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_REVERSE>, dim3(grid), dim3(256), 0, stream, a);
+    else if (a.mode == MULTI_MODE_INIT) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_INIT>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_QSAMPLE>, dim3(grid), dim3(256), 0, stream, a);
     CLAVA_CHECK_LAUNCH("clava_multinomial_step");
     return CLAVA_OK;
 }

@@ -8,41 +8,30 @@
 // reproducible from run to run (no float atomics).
 #include "rng.h"
 #include "step.h"
+#include "wave.h"
 
 namespace {
 
 constexpr float LOG_TINY = -69.07755279541016f;
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float log_add_exp(float x, float y) {
-    const float m = fmaxf(x, y);
-    return m + logf(1.0f + expf(-fabsf(x - y)));
-}
-
 // ---------------------------------------------------------------------------------------------- Gaussian MSE loss
 // loss_rows[b] = mean_c (noise - out)^2 ; d_out[b, c] = 2 (out - noise) / (n_num * B)     (:287-288 and its backward)
-__global__ void __launch_bounds__(256) gauss_mse_kernel(int B, int n, const float* __restrict__ out, int ld_out,
+// G lanes per row (G = the power of two covering n_num, at most 64): coalesced row segments, fixed-order lane sum.
+__global__ void __launch_bounds__(256) gauss_mse_kernel(int B, int n, int G, const float* __restrict__ out, int ld_out,
                                                         const float* __restrict__ noise, float* __restrict__ loss_rows,
                                                         float* __restrict__ d_out, int ld_d) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= B) return;
+    const int sub = threadIdx.x & (G - 1);
+    const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (row >= B) return;                          // whole groups leave together (G divides 64)
     const float gscale = 2.0f / ((float)n * (float)B);
     float acc = 0.f;
-    for (int c = 0; c < n; ++c) {
+    for (int c = sub; c < n; c += G) {
         const float d = noise[(size_t)row * n + c] - out[(size_t)row * ld_out + c];
         acc += d * d;
         d_out[(size_t)row * ld_d + c] = -d * gscale;
     }
-    loss_rows[row] = acc / (float)n;
+    for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0) loss_rows[row] = acc / (float)n;
 }
 
 // ---------------------------------------------------------------------------------------------- multinomial loss
@@ -59,94 +48,195 @@ struct MLossArgs {
     float* d_logits; int ld_d;            // gradient of mean_b( sum_f loss_terms / m ) w.r.t. logits
 };
 
+// Per-block (wave-uniform) quantities.  Everything that depends on a class only through "is it the clean category" /
+// "is it the noised category" takes two values per block and is evaluated once here, not once per class.
 struct LBlock {
     const float* lg;
+    float* d;
     int K, hot0, hott, t;
-    float mx, lsum, logk;
-    float lca_p, l1mca_p, la_t, l1ma_t, lca_T, l1mca_T;
-    __device__ __forceinline__ float lp(int c) const { return (lg[c] - mx) - lsum; }                       // predict_start
-    __device__ __forceinline__ float q1(int c) const {                                                     // q_pred_one_timestep(x_t)
-        return log_add_exp((c == hott ? 0.f : LOG_TINY) + la_t, l1ma_t - logk);
+    float mx, lsum;
+    float lca_p, uni_p;            // log cumprod alpha at t-1; log(1 - cumprod alpha_{t-1}) - log K
+    float q1_hot, q1_cold;         // q_pred_one_timestep(x_t) of the noised / any other category
+    float evt_hot, evt_cold;       // q_pred(x_0, t-1) (identity at t = 0) of the clean / any other category
+    float klp_hot, klp_cold;       // prior-KL terms exp(lq) (lq + log K) of the clean / any other category
+    __device__ __forceinline__ float q1(int c) const { return c == hott ? q1_hot : q1_cold; }
+    __device__ __forceinline__ float un_true(int c) const { return (c == hot0 ? evt_hot : evt_cold) + q1(c); }
+    __device__ __forceinline__ float ev(float lstart) const {                  // q_pred(., t-1) or identity at t = 0
+        return t == 0 ? lstart : log_add_exp(lstart + lca_p, uni_p);
     }
-    __device__ __forceinline__ float ev(float lstart) const {                                              // q_pred(., t-1) or identity at t = 0
-        return t == 0 ? lstart : log_add_exp(lstart + lca_p, l1mca_p - logk);
-    }
-    __device__ __forceinline__ float un_model(int c) const { return ev(lp(c)) + q1(c); }
-    __device__ __forceinline__ float un_true(int c) const { return ev(c == hot0 ? 0.f : LOG_TINY) + q1(c); }
 };
+
+// One block of up to 64 * NCH classes held in registers (logit, ev(log-softmax), true-posterior weight / gradient):
+// HBM sees each logit once and each gradient once; ten transcendentals per class.
+template <int NCH>
+__device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b, int lane, size_t pair) {
+    float v[NCH], e[NCH], w[NCH];
+    const int K = b.K;
+    float m1 = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j == 0 || j * 64 < K) {
+            const int c = lane + 64 * j;
+            v[j] = (c < K) ? b.lg[c] : -INFINITY;
+            m1 = fmaxf(m1, v[j]);
+        }
+    }
+    b.mx = group_max<64>(m1);
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (j == 0 || j * 64 < K) sm += exp_nonpos(v[j] - b.mx);
+    b.lsum = log_pos(group_sum<64>(sm));
+    // normalisers of the model and true posteriors (direct per-block log-sum-exp)
+    float mm = -INFINITY, mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j == 0 || j * 64 < K) {
+            const int c = lane + 64 * j;
+            v[j] = (v[j] - b.mx) - b.lsum;                                       // predict_start
+            e[j] = b.ev(v[j]);
+            if (c < K) { mm = fmaxf(mm, e[j] + b.q1(c)); mt = fmaxf(mt, b.un_true(c)); }
+        }
+    }
+    mm = group_max<64>(mm); mt = group_max<64>(mt);
+    float sm_m = 0.f, sm_t = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j == 0 || j * 64 < K) {
+            const int c = lane + 64 * j;
+            if (c < K) { sm_m += exp_nonpos((e[j] + b.q1(c)) - mm); sm_t += exp_nonpos(b.un_true(c) - mt); }
+        }
+    }
+    const float lse_m = mm + log_pos(group_sum<64>(sm_m)), lse_t = mt + log_pos(group_sum<64>(sm_t));
+    // loss terms: KL(true || model) (t > 0) or decoder NLL (t == 0) (:555-572), and the prior KL (:544-553)
+    float W = 0.f, loss = 0.f, klp = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j == 0 || j * 64 < K) {
+            const int c = lane + 64 * j;
+            w[j] = 0.f;
+            if (c < K) {
+                const float lm = (e[j] + b.q1(c)) - lse_m;
+                if (b.t == 0) {
+                    w[j] = (c == b.hot0) ? 1.0f : 1e-30f;                        // exp(log_x_start)
+                    loss -= w[j] * lm;
+                } else {
+                    const float lt = b.un_true(c) - lse_t;
+                    w[j] = exp_nonpos(lt);
+                    loss += w[j] * (lt - lm);
+                }
+                W += w[j];
+                klp += (c == b.hot0) ? b.klp_hot : b.klp_cold;
+            }
+        }
+    }
+    W = group_sum<64>(W); loss = group_sum<64>(loss); klp = group_sum<64>(klp);
+    if (lane == 0) a.loss_terms[pair] = loss / a.pt + klp;
+    // backward: d loss / d un_model(j) = -w(j) + W * exp(lm(j)); through ev (sigmoid of the log-add-exp) and log-softmax
+    float S = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j == 0 || j * 64 < K) {
+            const int c = lane + 64 * j;
+            if (c < K) {
+                const float lm = (e[j] + b.q1(c)) - lse_m;
+                const float g_un = -w[j] + W * exp_nonpos(lm);
+                w[j] = g_un * (b.t == 0 ? 1.0f : exp_nonpos((v[j] + b.lca_p) - e[j]));
+                S += w[j];
+            }
+        }
+    }
+    S = group_sum<64>(S);
+    const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        if (j == 0 || j * 64 < K) {
+            const int c = lane + 64 * j;
+            if (c < K) b.d[c] = (w[j] - exp_nonpos(v[j]) * S) * scale;
+        }
+    }
+}
+
+// Blocks beyond 1024 classes: the same passes, streaming over the classes and recomputing per pass.
+__device__ __forceinline__ void loss_block_streamed(const MLossArgs& a, LBlock& b, int lane, size_t pair) {
+    const int K = b.K;
+    float m1 = -INFINITY;
+    for (int c = lane; c < K; c += 64) m1 = fmaxf(m1, b.lg[c]);
+    b.mx = group_max<64>(m1);
+    float sm = 0.f;
+    for (int c = lane; c < K; c += 64) sm += exp_nonpos(b.lg[c] - b.mx);
+    b.lsum = log_pos(group_sum<64>(sm));
+    auto lp = [&](int c) { return (b.lg[c] - b.mx) - b.lsum; };
+    auto un_model = [&](int c) { return b.ev(lp(c)) + b.q1(c); };
+    float mm = -INFINITY, mt = -INFINITY;
+    for (int c = lane; c < K; c += 64) { mm = fmaxf(mm, un_model(c)); mt = fmaxf(mt, b.un_true(c)); }
+    mm = group_max<64>(mm); mt = group_max<64>(mt);
+    float sm_m = 0.f, sm_t = 0.f;
+    for (int c = lane; c < K; c += 64) { sm_m += exp_nonpos(un_model(c) - mm); sm_t += exp_nonpos(b.un_true(c) - mt); }
+    const float lse_m = mm + log_pos(group_sum<64>(sm_m)), lse_t = mt + log_pos(group_sum<64>(sm_t));
+    auto weight = [&](int c) { return (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : exp_nonpos(b.un_true(c) - lse_t); };
+    float W = 0.f, loss = 0.f, klp = 0.f;
+    for (int c = lane; c < K; c += 64) {
+        const float lm = un_model(c) - lse_m, w = weight(c);
+        if (b.t == 0) loss -= w * lm;
+        else loss += w * ((b.un_true(c) - lse_t) - lm);
+        W += w;
+        klp += (c == b.hot0) ? b.klp_hot : b.klp_cold;
+    }
+    W = group_sum<64>(W); loss = group_sum<64>(loss); klp = group_sum<64>(klp);
+    if (lane == 0) a.loss_terms[pair] = loss / a.pt + klp;
+    auto g_lp = [&](int c, float lpc) {
+        const float evc = b.ev(lpc);
+        const float lm = (evc + b.q1(c)) - lse_m;
+        return (-weight(c) + W * exp_nonpos(lm)) * (b.t == 0 ? 1.0f : exp_nonpos((lpc + b.lca_p) - evc));
+    };
+    float S = 0.f;
+    for (int c = lane; c < K; c += 64) S += g_lp(c, lp(c));
+    S = group_sum<64>(S);
+    const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
+    for (int c = lane; c < K; c += 64) {
+        const float lpc = lp(c);
+        b.d[c] = (g_lp(c, lpc) - exp_nonpos(lpc) * S) * scale;
+    }
+}
 
 __global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
     const int lane = threadIdx.x & 63;
     const long long n_pairs = (long long)a.B * a.m;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    if (wave0 >= n_pairs) return;
     const int T = a.s.T;
-    for (long long pair = wave0; pair < n_pairs; pair += n_waves) {
-        const int row = (int)(pair / a.m), f = (int)(pair - (long long)row * a.m);
-        const int o = a.offsets[f];
+    const float lca_T = a.s.log_cumprod_alpha[T - 1], l1mca_T = a.s.log_1_min_cumprod_alpha[T - 1];
+    // (row, feature) advance by n_waves pairs per iteration without a division in the loop
+    int row = (int)(wave0 / a.m), f = (int)(wave0 - (long long)row * a.m);
+    const int d_row = (int)(n_waves / a.m), d_f = (int)(n_waves - (long long)d_row * a.m);
+    for (; row < a.B; row += d_row, f += d_f) {
+        if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
+        const size_t pair = (size_t)row * a.m + f;
+        const int o = __builtin_amdgcn_readfirstlane(a.offsets[f]);
         LBlock b;
-        b.K = a.offsets[f + 1] - o;
-        b.logk = a.log_k[f];
-        b.t = (int)a.t_rows[row];
-        b.hot0 = a.idx0[(size_t)row * a.m + f];
-        b.hott = a.idxt[(size_t)row * a.m + f];
+        b.K = __builtin_amdgcn_readfirstlane(a.offsets[f + 1]) - o;
+        const float logk = a.log_k[f];
+        b.t = __builtin_amdgcn_readfirstlane((int)a.t_rows[row]);
+        b.hot0 = __builtin_amdgcn_readfirstlane(a.idx0[pair]);
+        b.hott = __builtin_amdgcn_readfirstlane(a.idxt[pair]);
         b.lg = a.logits + (size_t)row * a.ld_logits + o;
+        b.d = a.d_logits + (size_t)row * a.ld_d + o;
         const int tp = max(b.t - 1, 0);
-        b.lca_p = a.s.log_cumprod_alpha[tp];   b.l1mca_p = a.s.log_1_min_cumprod_alpha[tp];
-        b.la_t = a.s.log_alpha[b.t];           b.l1ma_t = a.s.log_1_min_alpha[b.t];
-        b.lca_T = a.s.log_cumprod_alpha[T - 1]; b.l1mca_T = a.s.log_1_min_cumprod_alpha[T - 1];
-        // log-softmax statistics of the logits
-        float mx = -INFINITY;
-        for (int c = lane; c < b.K; c += 64) mx = fmaxf(mx, b.lg[c]);
-        b.mx = wave_max(mx);
-        float sm = 0.f;
-        for (int c = lane; c < b.K; c += 64) sm += expf(b.lg[c] - b.mx);
-        b.lsum = logf(wave_sum(sm));
-        // normalisers of the model and true posteriors (direct per-block log-sum-exp)
-        float mm = -INFINITY, mt = -INFINITY;
-        for (int c = lane; c < b.K; c += 64) { mm = fmaxf(mm, b.un_model(c)); mt = fmaxf(mt, b.un_true(c)); }
-        mm = wave_max(mm); mt = wave_max(mt);
-        float sm_m = 0.f, sm_t = 0.f;
-        for (int c = lane; c < b.K; c += 64) { sm_m += expf(b.un_model(c) - mm); sm_t += expf(b.un_true(c) - mt); }
-        const float lse_m = mm + logf(wave_sum(sm_m)), lse_t = mt + logf(wave_sum(sm_t));
-        // loss terms: KL(true || model) (t > 0) or decoder NLL (t == 0) (:555-572), and the prior KL (:544-553)
-        float W = 0.f, loss = 0.f, klp = 0.f;
-        for (int c = lane; c < b.K; c += 64) {
-            const float lm = b.un_model(c) - lse_m;
-            if (b.t == 0) {
-                const float w = (c == b.hot0) ? 1.0f : 1e-30f;        // exp(log_x_start)
-                W += w;
-                loss -= w * lm;
-            } else {
-                const float lt = b.un_true(c) - lse_t;
-                const float w = expf(lt);
-                W += w;
-                loss += w * (lt - lm);
-            }
-            const float lq = log_add_exp((c == b.hot0 ? 0.f : LOG_TINY) + b.lca_T, b.l1mca_T - b.logk);
-            klp += expf(lq) * (lq + b.logk);
-        }
-        W = wave_sum(W); loss = wave_sum(loss); klp = wave_sum(klp);
-        if (lane == 0) a.loss_terms[(size_t)row * a.m + f] = loss / a.pt + klp;
-        // backward: d loss / d un_model(j) = -w(j) + W * exp(lm(j)); through ev (sigmoid of the log-add-exp) and log-softmax
-        float S = 0.f;
-        for (int c = lane; c < b.K; c += 64) {
-            const float lpc = b.lp(c), evc = b.ev(lpc);
-            const float lm = (evc + b.q1(c)) - lse_m;
-            const float w = (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : expf(b.un_true(c) - lse_t);
-            const float g_un = -w + W * expf(lm);
-            S += g_un * (b.t == 0 ? 1.0f : expf((lpc + b.lca_p) - evc));
-        }
-        S = wave_sum(S);
-        const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
-        float* d = a.d_logits + (size_t)row * a.ld_d + o;
-        for (int c = lane; c < b.K; c += 64) {
-            const float lpc = b.lp(c), evc = b.ev(lpc);
-            const float lm = (evc + b.q1(c)) - lse_m;
-            const float w = (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : expf(b.un_true(c) - lse_t);
-            const float g_lp = (-w + W * expf(lm)) * (b.t == 0 ? 1.0f : expf((lpc + b.lca_p) - evc));
-            d[c] = (g_lp - expf(lpc) * S) * scale;
-        }
+        b.lca_p = a.s.log_cumprod_alpha[tp];
+        b.uni_p = a.s.log_1_min_cumprod_alpha[tp] - logk;
+        const float la_t = a.s.log_alpha[b.t], uni_t = a.s.log_1_min_alpha[b.t] - logk;
+        b.q1_hot = log_add_exp(0.f + la_t, uni_t);
+        b.q1_cold = log_add_exp(LOG_TINY + la_t, uni_t);
+        b.evt_hot = b.ev(0.f);
+        b.evt_cold = b.ev(LOG_TINY);
+        const float lq_hot = log_add_exp(0.f + lca_T, l1mca_T - logk), lq_cold = log_add_exp(LOG_TINY + lca_T, l1mca_T - logk);
+        b.klp_hot = exp_nonpos(lq_hot) * (lq_hot + logk);
+        b.klp_cold = exp_nonpos(lq_cold) * (lq_cold + logk);
+        if (b.K <= 256) loss_block_cached<4>(a, b, lane, pair);
+        else if (b.K <= 1024) loss_block_cached<16>(a, b, lane, pair);
+        else loss_block_streamed(a, b, lane, pair);
     }
 }
 
@@ -282,7 +372,10 @@ int clava_gauss_mse_loss_f32(int B, int n_num, const float* model_out, int ld_ou
                              float* d_out, int ld_d, void* stream) {
     CLAVA_CHECK_ARG(B > 0 && n_num > 0 && model_out && noise && loss_rows && d_out, "gauss_mse_loss: bad arguments");
     ProfScope prof(PROF_LOSS, 0.0, 12.0 * B * n_num, (hipStream_t)stream);
-    hipLaunchKernelGGL(gauss_mse_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n_num, model_out, ld_out,
+    int G = 1;
+    while (G < n_num && G < 64) G <<= 1;
+    const long long blocks = ((long long)B * G + 255) / 256;
+    hipLaunchKernelGGL(gauss_mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, n_num, G, model_out, ld_out,
                        noise, loss_rows, d_out, ld_d);
     CLAVA_CHECK_LAUNCH("clava_gauss_mse_loss_f32");
     return CLAVA_OK;

@@ -1,0 +1,79 @@
+// Wavefront-group reductions on the DPP path and the lean exp / log used by the categorical kernels
+// (diffusion_step.hip, train.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+// Reductions over a group of G lanes without LDS traffic: xor-1 / xor-2 quad permutes and the two row mirrors on the
+// DPP path (16 lanes), then one shuffle (G = 32) or four lane reads into scalar registers (G = 64, result wave-uniform).
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+template <int G> __device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    if (G >= 16) v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    if (G == 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (G == 64) {
+        const int i = __float_as_int(v);
+        v = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+    }
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_sum(float v) {       // fixed order: deterministic
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    if (G >= 16) v += dpp_f<DPP_ROW_MIRROR>(v);
+    if (G == 32) v += __shfl_xor(v, 16, 64);
+    if (G == 64) {
+        const int i = __float_as_int(v);
+        v = (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+            (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+    }
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_min(int v) {
+    v = min(v, dpp_i<DPP_XOR1>(v));
+    v = min(v, dpp_i<DPP_XOR2>(v));
+    v = min(v, dpp_i<DPP_HALF_MIRROR>(v));
+    if (G >= 16) v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
+    if (G == 32) v = min(v, __shfl_xor(v, 16, 64));
+    if (G == 64)
+        v = min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    return v;
+}
+
+// e^x for x <= 0: the library routine's two-term argument reduction without its overflow / denormal-result paths
+// (arguments here are differences to a maximum); below -200 the result is 0 like the exact value in float32.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    x = fmaxf(x, -200.0f);
+    const float log2e = __int_as_float(0x3fb8aa3b);
+    const float ph = x * log2e;
+    float pl = __builtin_fmaf(x, log2e, -ph);
+    pl = __builtin_fmaf(x, __int_as_float(0x32a5705f), pl);
+    const float r = __builtin_amdgcn_exp2f(ph);
+    return __builtin_fmaf(r, pl * 0.693147182f, r);
+}
+// log(x) for normal, finite x > 0: bit-identical to logf there (same hardware log2 and two-term product), without the
+// denormal pre-scaling and the infinity select
+__device__ __forceinline__ float log_pos(float x) {
+    const float l = __builtin_amdgcn_logf(x);
+    const float ln2 = __int_as_float(0x3f317217);
+    const float ph = l * ln2;
+    float pl = __builtin_fmaf(l, ln2, -ph);
+    pl = __builtin_fmaf(l, __int_as_float(0x3377d1cf), pl);
+    return ph + pl;
+}
+// log_add_exp (tab_ddpm/utils.py:104-106): one of the two exponentials is exp(0) = 1 exactly
+__device__ __forceinline__ float log_add_exp(float x, float y) {
+    const float m = fmaxf(x, y);
+    return m + log_pos(1.0f + exp_nonpos(-fabsf(x - y)));
+}
+
+}  // namespace
