@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--fit-steps", type=int, default=600, help="Trainer steps that fit the denoiser to the synthetic table before sampling")
     ap.add_argument("--gemm", choices=["f16x3", "f32"], default="f16x3",
                     help="layer kernels of the sampling loop: split-f16 on the f16 matrix cores (float32-level accuracy) or float32-input MFMA")
+    ap.add_argument("--no-scale-sweep", action="store_true", help="skip the step-kernel / scale-sweep (100 num + 50 cat columns) legs")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra chain timed on the float32-input MFMA kernels")
     args = ap.parse_args()
 
@@ -465,6 +466,22 @@ def main():
         clf_train = classifier_train_bench(device, args.n_num, args.clusters, T, 4096, args.clf_train_steps, 10,
                                            0 if args.no_cpu_baseline else 3)
 
+    # single-GPU side legs at the scale-sweep shape (BASELINE.json configs[4]): the fused step kernels against the HBM
+    # roofline (north_star: "achieved HBM GB/s for the step kernel"), and the training step / reverse step of that table
+    step_kernels = sweep = None
+    if rank == 0 and world == 1 and not args.no_scale_sweep:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_scale_sweep
+        import bench_step
+        step_kernels = bench_step.measure(B=20000, K=bench_scale_sweep.classes())
+        step_kernels["peak_gbps"] = 8000.0
+        step_kernels["note"] = ("clava_gauss_step_f32 / clava_multinomial_step_f32 (reverse mode, in-kernel Philox noise, next denoiser "
+                                "input written) at 100 numeric + 50 categorical columns; bytes = DESIGN.md section 4; the categorical "
+                                "kernel is bound by its 5 transcendentals per class, not by HBM")
+        split_nets.set_gemm_mode("f16x3")
+        sweep = bench_scale_sweep.measure(batch=4096, train_steps=60, breakdown=True)
+        split_nets.set_gemm_mode(args.gemm)
+
     rows = world * B * args.steps
     value = rows / elapsed
     out = {
@@ -483,6 +500,8 @@ def main():
         "api_path_incl_pcie": api,
         "gmm_estep": gmm,
         "classifier_train": clf_train,
+        "step_kernels": step_kernels,
+        "scale_sweep": sweep,
         "sample_absmax": round(x_absmax, 3),
         "f16x3_fallbacks": split_nets.fallback_count,
     }
