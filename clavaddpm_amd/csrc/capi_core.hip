@@ -155,6 +155,36 @@ int clava_split_unpack_f32(const void* src, long long pitch, long long rows, int
     return clava_launch_split_unpack((const char*)src, pitch, rows, cols, shift, dst, ld, (hipStream_t)stream);
 }
 
+int clava_split_transpose(const void* src, long long pitch_src, long long rows, int cols, void* dst, long long pitch_dst, void* stream) {
+    return clava_launch_split_transpose((const char*)src, pitch_src, rows, cols, (char*)dst, pitch_dst, (hipStream_t)stream);
+}
+
+int clava_gemm_wgrad_f16x3(const void* dyt, long long pitch_dyt, int shift_dy, const void* xt, long long pitch_xt, int shift_x,
+                           float* dw_slabs, int lddw, long long slab_stride, int M, int N_out, int K_in, int splits,
+                           int tile_config, void* stream) {
+    CLAVA_CHECK_ARG(M > 0 && N_out > 0 && K_in > 0 && splits >= 1 && dw_slabs, "gemm_wgrad_f16x3: bad arguments");
+    CLAVA_CHECK_ARG(shift_dy + shift_x >= -60 && shift_dy + shift_x <= 60, "gemm_wgrad_f16x3: shift out of range");
+    SplitGemmArgs g;
+    g.A = (const char*)dyt; g.W = (const char*)xt;
+    g.M = N_out; g.N = K_in; g.Kp = (M + 31) & ~31; g.K = M;
+    g.pitchA = pitch_dyt; g.pitchW = pitch_xt;
+    g.bias = nullptr; g.bias2 = nullptr; g.act = CLAVA_ACT_NONE;
+    g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
+    g.scale_acc = ldexpf(1.f, -(shift_dy + shift_x));
+    g.alpha = 1.f; g.scale_out = 1.f;
+    g.out_split = nullptr; g.pitchOut = 0;
+    g.out_f32 = dw_slabs; g.ldc = lddw;
+    g.overflow = nullptr;
+    g.tiles_m = g.tiles_n = 0;
+    const int nkb = g.Kp >> 5;
+    g.kb_per_slab = (nkb + splits - 1) / splits;
+    g.slabs = splits;
+    CLAVA_CHECK_ARG((long long)(splits - 1) * g.kb_per_slab < nkb, "gemm_wgrad_f16x3: %d splits leave empty slabs at batch %d", splits, M);
+    g.slab_stride = slab_stride;
+    if (splits == 1) { g.slabs = 1; g.kb_per_slab = 0; }
+    return clava_launch_gemm_f16x3(g, tile_config, (hipStream_t)stream);
+}
+
 int clava_gemm_f16x3_config_count_(void) { return clava_gemm_f16x3_config_count(); }
 
 int clava_gemm_f16x3(const void* x, long long pitch_x, int shift_x, const void* w, long long pitch_w, int shift_w,

@@ -57,7 +57,14 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     const int tile = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (bid >> 3);
     const int m0 = (tile / g.tiles_n) * BM;
     const int n0 = (tile % g.tiles_n) * BN;
-    const int nkb = g.Kp >> 5;
+    int nkb = g.Kp >> 5;
+    long long kbyte0 = 0;                                     // byte offset of this slab's first k block inside a row
+    if (g.slabs > 1) {
+        const int kb0 = blockIdx.y * g.kb_per_slab;
+        nkb = min(nkb - kb0, g.kb_per_slab);
+        kbyte0 = (long long)kb0 * 128;
+        g.out_f32 += (long long)blockIdx.y * g.slab_stride;
+    }
 
     // ---- staging sources: lane i of a group fills LDS row 8*group + (i >> 3), chunk slot (i & 7).  Every wave issues
     // exactly Q DMAs per stage (a wave without a last group re-issues its previous one: same source, same destination)
@@ -74,10 +81,10 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
             // LDS row 32*p + 16*b + 4*q + rr holds output column 32*p + 8*q + 4*b + rr (epilogue: 8 consecutive columns per lane)
             const int pr = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
             const int gr = min(n0 + pr, g.N - 1);
-            src[q] = g.W + (long long)gr * g.pitchW + sw;
+            src[q] = g.W + (long long)gr * g.pitchW + sw + kbyte0;
         } else {
             const int gr = min(m0 + (r - BN), g.M - 1);
-            src[q] = g.A + (long long)gr * g.pitchA + sw;
+            src[q] = g.A + (long long)gr * g.pitchA + sw + kbyte0;
         }
     }
     char* const st = smem + wave * 1024;
@@ -257,6 +264,54 @@ __global__ void __launch_bounds__(256) split_pack_kernel(const float* __restrict
     if (ovf && overflow) *overflow = 1;
 }
 
+// Split rows [rows][cols] -> split rows [cols][rows] (the batch-major operands of the weight-gradient products).
+// One workgroup moves a 64 x 64 tile of both planes through LDS: 128-byte reads along the source rows, 128-byte writes
+// along the destination rows; elements beyond the source's rows / columns are written as zeros (pad of the contraction).
+__global__ void __launch_bounds__(256) split_transpose_kernel(const char* __restrict__ src, long long pitch_src, long long rows, int cols,
+                                                              char* __restrict__ dst, long long pitch_dst) {
+    __shared__ unsigned short t_hi[64][66], t_lo[64][66];
+    const long long r0 = (long long)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int colsp = (cols + 31) & ~31;
+    // read: thread -> (row r0 + tid / 4, 16-column group tid % 4): two 16-byte loads per plane
+    {
+        const int r = threadIdx.x >> 2, cg = (threadIdx.x & 3) * 16;
+        const long long row = r0 + r;
+        const int c = c0 + cg;
+        unsigned short hi[16], lo[16];
+        if (row < rows && c < colsp) {
+            const char* p = src + row * pitch_src + (long long)(c >> 5) * 128 + ((c & 31) << 1);
+            *reinterpret_cast<uint4*>(hi) = *reinterpret_cast<const uint4*>(p);
+            *reinterpret_cast<uint4*>(hi + 8) = *reinterpret_cast<const uint4*>(p + 16);
+            *reinterpret_cast<uint4*>(lo) = *reinterpret_cast<const uint4*>(p + 64);
+            *reinterpret_cast<uint4*>(lo + 8) = *reinterpret_cast<const uint4*>(p + 80);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hi[i] = lo[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { t_hi[cg + i][r] = hi[i]; t_lo[cg + i][r] = lo[i]; }
+    }
+    __syncthreads();
+    // write: thread -> (destination row c0 + tid / 4, 16 source rows (tid % 4) * 16 ..)
+    {
+        const int cr = threadIdx.x >> 2, rg = (threadIdx.x & 3) * 16;
+        const int c = c0 + cr;
+        const long long rr = r0 + rg;
+        const long long rowsp = (rows + 31) & ~31LL;
+        if (c < cols && rr < rowsp) {
+            unsigned short hi[16], lo[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { hi[i] = t_hi[cr][rg + i]; lo[i] = t_lo[cr][rg + i]; }
+            char* p = dst + (long long)c * pitch_dst + (rr >> 5) * 128 + ((rr & 31) << 1);
+            *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(hi);
+            *reinterpret_cast<uint4*>(p + 16) = *reinterpret_cast<const uint4*>(hi + 8);
+            *reinterpret_cast<uint4*>(p + 64) = *reinterpret_cast<const uint4*>(lo);
+            *reinterpret_cast<uint4*>(p + 80) = *reinterpret_cast<const uint4*>(lo + 8);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) split_unpack_kernel(const char* __restrict__ src, long long pitch, long long rows, int cols,
                                                            float inv_scale, float* __restrict__ dst, long long ld) {
     const long long total = rows * cols;
@@ -329,7 +384,15 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     CLAVA_CHECK_ARG(!g.out_f32 || g.ldc >= g.N, "gemm_f16x3: ldc too small");
     CLAVA_CHECK_ARG(g.act == CLAVA_ACT_NONE || g.act == CLAVA_ACT_RELU || g.act == CLAVA_ACT_LEAKY, "gemm_f16x3: activation %d", g.act);
     CLAVA_CHECK_ARG(cfg < kNumCfgs, "gemm_f16x3: tile configuration %d does not exist", cfg);
-    if (cfg < 0) cfg = pick_cfg(g.M, g.N, g.Kp);
+    const int slabs = g.slabs > 1 ? g.slabs : 1;
+    if (slabs > 1) {
+        CLAVA_CHECK_ARG(g.out_f32 && !g.out_split && !g.mask && !g.bias && !g.bias2 && g.act == CLAVA_ACT_NONE,
+                        "gemm_f16x3: a slab product writes plain float32 partial sums only");
+        CLAVA_CHECK_ARG(g.kb_per_slab > 0 && (long long)(slabs - 1) * g.kb_per_slab < (g.Kp >> 5) && (long long)slabs * g.kb_per_slab >= (g.Kp >> 5),
+                        "gemm_f16x3: %d slabs of %d k blocks do not cover Kp=%d", slabs, g.kb_per_slab, g.Kp);
+        CLAVA_CHECK_ARG(g.slab_stride >= (long long)(g.M - 1) * g.ldc + g.N, "gemm_f16x3: slab stride too small");
+    }
+    if (cfg < 0) cfg = pick_cfg(g.M * slabs, g.N, slabs > 1 ? g.kb_per_slab * 32 : g.Kp);
     const TileCfg& tc = kCfgs[cfg];
     const int lds = tc.ns * (tc.bn + tc.bm) * 128;
     int dev = 0;
@@ -347,7 +410,7 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     const double flops = 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp);
     const double bytes = 4.0 * ((double)g.M * g.Kp + (double)g.N * g.Kp + (double)g.M * g.N);
     ProfScope prof(PROF_GEMM_F16X3 + cfg, flops, bytes, stream);
-    hipLaunchKernelGGL(tc.kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+    hipLaunchKernelGGL(tc.kernel, dim3(g.tiles_m * g.tiles_n, slabs), dim3(512), lds, stream, g);
     CLAVA_CHECK_LAUNCH("clava_gemm_f16x3");
     return CLAVA_OK;
 }
@@ -365,6 +428,21 @@ int clava_launch_split_pack(const float* src, long long ld, long long rows, int 
     hipLaunchKernelGGL(split_pack_kernel, dim3(blocks), dim3(256), 0, stream, src, transposed ? 1LL : ld, transposed ? ld : 1LL, rows, cols,
                        groups, ldexpf(1.f, shift), dst, pitch, overflow);
     CLAVA_CHECK_LAUNCH("clava_split_pack");
+    return CLAVA_OK;
+}
+
+int clava_launch_split_transpose(const char* src, long long pitch_src, long long rows, int cols, char* dst, long long pitch_dst,
+                                 hipStream_t stream) {
+    CLAVA_CHECK_ARG(src && dst && rows > 0 && cols > 0, "split_transpose: bad arguments");
+    const int colsp = (cols + 31) & ~31;
+    const long long rowsp = (rows + 31) & ~31LL;
+    CLAVA_CHECK_ARG(pitch_src >= 4LL * colsp && pitch_src % 16 == 0 && aligned(src, 16), "split_transpose: source rows must be 16-byte aligned, >= 4*round_up(cols,32) bytes apart");
+    CLAVA_CHECK_ARG(pitch_dst >= 4LL * rowsp && pitch_dst % 16 == 0 && aligned(dst, 16), "split_transpose: destination rows must be 16-byte aligned, >= 4*round_up(rows,32) bytes apart");
+    CLAVA_CHECK_ARG((rowsp + 63) / 64 <= 65535, "split_transpose: too many rows");
+    ProfScope prof(PROF_MISC, 0.0, 8.0 * rows * colsp, stream);
+    hipLaunchKernelGGL(split_transpose_kernel, dim3((colsp + 63) / 64, (unsigned)((rowsp + 63) / 64)), dim3(256), 0, stream, src, pitch_src,
+                       rows, cols, dst, pitch_dst);
+    CLAVA_CHECK_LAUNCH("clava_split_transpose");
     return CLAVA_OK;
 }
 

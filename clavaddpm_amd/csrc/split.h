@@ -37,6 +37,10 @@ struct SplitGemmArgs {
     int ldc;
     int* overflow;      // set to 1 when an output magnitude exceeds the float16 range; or null
     int tiles_m, tiles_n;
+    // weight-gradient products: the contraction (batch) axis is cut into `slabs` ranges of kb_per_slab 32-deep blocks;
+    // blockIdx.y = slab, whose partial product goes to out_f32 + slab * slab_stride floats.  slabs <= 1: one product.
+    int slabs = 1, kb_per_slab = 0;
+    long long slab_stride = 0;
 };
 
 // cfg < 0: pick the tile configuration for the shape; otherwise force configuration `cfg` (tools/bench_f16x3.py)
@@ -45,5 +49,8 @@ int clava_gemm_f16x3_config_count();
 // transposed: the packed matrix [rows, cols] is the transpose of the stored one (element (r, c) = src[c * ld + r])
 int clava_launch_split_pack(const float* src, long long ld, long long rows, int cols, int shift, char* dst,
                             long long pitch, int* overflow, hipStream_t stream, bool transposed = false);
+// dst[cols][rows] = src[rows][cols]^T, both split rows (planes are moved, not re-rounded; pad rows/columns become zeros)
+int clava_launch_split_transpose(const char* src, long long pitch_src, long long rows, int cols, char* dst, long long pitch_dst,
+                                 hipStream_t stream);
 int clava_launch_split_unpack(const char* src, long long pitch, long long rows, int cols, int shift, float* dst,
                               long long ld, hipStream_t stream);

@@ -150,6 +150,35 @@ def split_pack_transposed(x, shift=0, overflow=None, out=None):
     return out
 
 
+def split_transpose(s, out=None):
+    """SplitTensor of the transpose (clava_split_transpose): planes moved as they are, same shift."""
+    if out is None:
+        out = split_empty(s.cols, s.rows, s.shift, s.buf.device)
+    elif (out.rows, out.cols) != (s.cols, s.rows):
+        raise _lib.ClavaHipError("split_transpose: `out` has another shape")
+    out.shift = s.shift
+    if s.rows and s.cols:
+        check(lib().clava_split_transpose(ptr(s.buf), _lib.c_long(s.pitch), _lib.c_long(s.rows), c_int(s.cols), ptr(out.buf),
+                                          _lib.c_long(out.pitch), stream_ptr()), "clava_split_transpose")
+    return out
+
+
+def linear_wgrad_f16x3(dyt, xt, splits, out, slab_stride, tile_config=-1):
+    """Partial products of dy.T @ x over `splits` batch ranges on the f16 matrix cores (clava_gemm_wgrad_f16x3):
+    dyt = dy^T [N_out, M], xt = x^T [K_in, M] as SplitTensors; fills `out` (slabs `slab_stride` floats apart, rows K_in apart)."""
+    n_out, M = dyt.rows, dyt.cols
+    k_in = xt.rows
+    if xt.cols != M:
+        raise _lib.ClavaHipError("linear_wgrad_f16x3: batch mismatch")
+    nkb = (M + 31) // 32
+    while splits > 1 and (splits - 1) * ((nkb + splits - 1) // splits) >= nkb:
+        splits -= 1
+    check(lib().clava_gemm_wgrad_f16x3(ptr(dyt.buf), _lib.c_long(dyt.pitch), c_int(dyt.shift), ptr(xt.buf), _lib.c_long(xt.pitch),
+                                       c_int(xt.shift), ptr(out), c_int(k_in), _lib.c_long(slab_stride), c_int(M), c_int(n_out),
+                                       c_int(k_in), c_int(splits), c_int(tile_config), stream_ptr()), "clava_gemm_wgrad_f16x3")
+    return splits
+
+
 def split_unpack(s):
     out = torch.empty((s.rows, s.cols), device=s.buf.device, dtype=torch.float32)
     if s.rows:

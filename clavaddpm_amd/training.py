@@ -11,6 +11,7 @@ Mirrors `mixed_loss` (`tab_ddpm/gaussian_multinomial_diffsuion.py:636-675`) and 
 `MLPDiffusion.forward` (`tab_ddpm/modules.py:451-460`).
 """
 import ctypes
+import os
 
 import torch
 
@@ -19,6 +20,7 @@ from ._lib import c_float, c_int, check, lib, ptr, require_cuda, stream_ptr
 from .tab_ddpm.modules import timestep_embedding
 
 c_ll = ctypes.c_longlong
+WGRAD_F16X3 = os.environ.get("CLAVA_WGRAD_F16X3", "1") != "0"   # hidden-block weight gradients on the split-f16 kernels
 GRAD_SPLITS = 8   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
 
@@ -231,23 +233,38 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     main = torch.cuda.current_stream()
     side = st.side_stream(dev)
     keep = []
+    # every slab must be written each step: the split product needs `splits` non-empty ranges of whole 32-row blocks
+    nkb = (M + 31) // 32
+    wgrad_split_ok = WGRAD_F16X3 and (splits - 1) * ((nkb + splits - 1) // splits) < nkb
 
-    def param_grads_async(prefix, dy, inp):
+    def param_grads_async(prefix, dy, inp, dy_split=None, inp_split=None):
         ev = torch.cuda.Event()
         ev.record(main)
-        keep.append((dy, inp))
+        keep.append((dy, inp, dy_split, inp_split))
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            param_grads(prefix, dy, inp)
+            if dy_split is not None and inp_split is not None and wgrad_split_ok:
+                # weight gradient on the f16 matrix cores: the batch is the contraction axis, so both operands are
+                # transposed (planes moved, not re-rounded); the bias gradient still sums the float32 copy
+                wi = layout.index[prefix + ".weight"]
+                dyt = ops.split_transpose(dy_split, out=st.buf(("T", prefix, "dy"), dy_split.cols, dy_split.rows, dev))
+                xt = ops.split_transpose(inp_split, out=st.buf(("T", prefix, "x"), inp_split.cols, inp_split.rows, dev))
+                ops.linear_wgrad_f16x3(dyt, xt, splits, slabs[:, layout.offsets[wi]:], total)
+                bi = layout.index[prefix + ".bias"]
+                check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(M), c_int(dy.shape[1]), c_int(splits),
+                                                   ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
+            else:
+                param_grads(prefix, dy, inp)
 
     # head (float32): parameter gradients and the gradient w.r.t. the last hidden pre-activation
     param_grads_async(names[n - 1], d_out, hs[n - 2])
     g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
     gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
     for l in range(n - 2, 0, -1):
-        param_grads_async(names[l], g, hs[l - 1])
+        param_grads_async(names[l], g, hs[l - 1], gs, hsplit[l - 1])
         w = ws[l].detach()
-        wt = ops.split_pack_transposed(w, st.shift_w[l], st.flag, out=st.buf(("wt", l), w.shape[1], w.shape[0], dev))
+        # W^T for the input gradient: the planes of the forward's packed weight, transposed (coalesced both ways)
+        wt = ops.split_transpose(st.bufs[("w", l)], out=st.buf(("wt", l), w.shape[1], w.shape[0], dev))
         if l - 1 >= 1:
             gs, g = ops.linear_f16x3(gs, wt, act_out=hsplit[l - 1], slope=0.0, both=True, out_shift=st.shift_g[l - 1],
                                      out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)

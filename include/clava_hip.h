@@ -99,6 +99,19 @@ int clava_gemm_f16x3(const void* x, long long pitch_x, int shift_x, const void* 
                      int* overflow, int tile_config, void* stream);
 int clava_gemm_f16x3_config_count_(void);
 
+/* dst[cols, rows] = src[rows, cols]^T, both split rows (the float16 planes are moved, not re-rounded; the shift is the
+ * source's).  Pad rows / columns of dst are zeros.  Pitches are multiples of 16 bytes. */
+int clava_split_transpose(const void* src, long long pitch_src, long long rows, int cols, void* dst, long long pitch_dst,
+                          void* stream);
+
+/* clava_gemm_wgrad_f32 on the f16 matrix cores: dw_slabs[s*slab_stride + n*lddw + k] = partial_s( dy[M,N_out]^T . x[M,K_in] ).
+ * dyt = dy^T as split rows [N_out, M] (shift_dy), xt = x^T as split rows [K_in, M] (shift_x): the batch is the contraction
+ * axis, cut into `splits` ranges of whole 32-row blocks (every range non-empty).  Replaces the weight-gradient half of
+ * loss.backward() (scripts/train.py:37) for the hidden blocks. */
+int clava_gemm_wgrad_f16x3(const void* dyt, long long pitch_dyt, int shift_dy, const void* xt, long long pitch_xt, int shift_x,
+                           float* dw_slabs, int lddw, long long slab_stride, int M, int N_out, int K_in, int splits,
+                           int tile_config, void* stream);
+
 /* ---- schedule tables ---------------------------------------------------------------------------------------
  * Device-resident tables of length T, built by the host exactly as GaussianMultinomialDiffusion.__init__ builds
  * them (tab_ddpm/gaussian_multinomial_diffsuion.py:105-156); model_variance is the "fixed-large" variance the

@@ -62,6 +62,9 @@ def measure(B=4096, n_num=100, K=None, T=1000, reps=20, device="cuda"):
 
 if __name__ == "__main__":
     import json
+    if "--profile" in sys.argv:           # one shape only, for rocprofv3 runs
+        print(json.dumps(measure(B=20000, reps=10)))
+        sys.exit(0)
     for B in (4096, 20000):
         print(json.dumps(measure(B=B)))
     print(json.dumps(measure(B=20000, K=[3, 5, 2, 7, 4, 10, 2, 6])))
