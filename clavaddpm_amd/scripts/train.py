@@ -129,7 +129,7 @@ class Trainer:
             gs = [None] * len(saved[4]) if st is not None else None
             _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs, collect=gs)
             if st is not None:
-                st.calibrate(net.stack()[0], saved[4], gs)
+                st.calibrate(net.stack()[0], saved[4], gs, x_in=x_in, d_out=d_out)
         else:
             model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
             loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)

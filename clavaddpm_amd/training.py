@@ -21,6 +21,7 @@ from .tab_ddpm.modules import timestep_embedding
 
 c_ll = ctypes.c_longlong
 WGRAD_F16X3 = os.environ.get("CLAVA_WGRAD_F16X3", "1") != "0"   # hidden-block weight gradients on the split-f16 kernels
+WIDE_END_LAYERS = int(os.environ.get("CLAVA_WIDE_END_LAYERS", "256"))   # D_in from which proj / head run split-f16 too (0 = never)
 GRAD_SPLITS = 8   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
 
@@ -155,8 +156,9 @@ class SplitTrainState:
             self.bufs[key] = b
         return b
 
-    def calibrate(self, ws, hs, gs):
-        """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step."""
+    def calibrate(self, ws, hs, gs, x_in=None, d_out=None):
+        """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step;
+        x_in / d_out (denoiser input, loss gradient) fix the scales of the wide end layers' operands."""
         from .split_nets import TARGET_LOG2, shift_for
         n = len(ws)
         if self.flag is None:
@@ -164,9 +166,13 @@ class SplitTrainState:
         elif int(self.flag.item()) != 0:
             raise _lib.ClavaHipError("split-f16 training: a tensor left the float16 range since the last calibration "
                                      "(magnitudes grew by more than 60x within %d steps)" % self.period)
+        zero = torch.zeros((), device=ws[0].device)
         stats = torch.stack([w.detach().abs().max() for w in ws] + [h.abs().max() for h in hs] +
-                            [gs[l].abs().max() if gs[l] is not None else torch.zeros((), device=ws[0].device) for l in range(n)])
+                            [gs[l].abs().max() if gs[l] is not None else zero for l in range(n)] +
+                            [x_in.abs().max() if x_in is not None else zero, d_out.abs().max() if d_out is not None else zero])
         v = stats.cpu().tolist()
+        self.shift_x = shift_for(v[3 * n], TARGET_LOG2 + 1)      # the log-one-hot columns are exactly 0 / -69.08
+        self.shift_d = shift_for(v[3 * n + 1], TARGET_LOG2)
         self.shift_w = [shift_for(x, 10) for x in v[:n]]
         self.shift_h = [shift_for(x, TARGET_LOG2) for x in v[n:2 * n]]
         self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:]]
@@ -186,7 +192,18 @@ def denoiser_forward_split(net, x_in, t, st):
     n = len(ws)
     dev = x_in.device
     B = x_in.shape[0]
-    h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)            # proj(x) + emb (modules.py:459), float32
+    # D_in-wide end layers (one-hot heavy tables, BASELINE.json configs[4]) go to the f16 matrix cores too; at a handful
+    # of columns they are a few MFLOP and stay on the float32 kernels
+    wide = WIDE_END_LAYERS > 0 and x_in.shape[1] >= WIDE_END_LAYERS and getattr(st, "shift_x", None) is not None
+    xs = None
+    if wide:
+        xs = ops.split_pack(x_in, st.shift_x, st.flag, out=st.buf(("x",), B, x_in.shape[1], dev))
+        w0 = ws[0].detach()
+        w0s = ops.split_pack(w0, st.shift_w[0], st.flag, out=st.buf(("w", 0), w0.shape[0], w0.shape[1], dev))
+        h = ops.linear_f16x3(xs, w0s, bs[0].detach(), out_f32=True, overflow=st.flag)
+        h.add_(emb)                               # per-row time embedding (the split kernel's row term is batch-constant)
+    else:
+        h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)        # proj(x) + emb (modules.py:459), float32
     hs = [h]
     hsplit = [ops.split_pack(h, st.shift_h[0], st.flag, out=st.buf(("h", 0), B, h.shape[1], dev))]
     wsp = []
@@ -194,7 +211,7 @@ def denoiser_forward_split(net, x_in, t, st):
         w = ws[l].detach()
         wsp.append(ops.split_pack(w, st.shift_w[l], st.flag, out=st.buf(("w", l), w.shape[0], w.shape[1], dev)))
         last = l == n - 2
-        if last:                                  # the head reads float32: no split copy of the last hidden activation
+        if last and not wide:                     # the head reads float32: no split copy of the last hidden activation
             hf = ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", out_f32=True, overflow=st.flag)
             hsplit.append(None)
         else:
@@ -202,15 +219,21 @@ def denoiser_forward_split(net, x_in, t, st):
                                        out=st.buf(("h", l), B, w.shape[0], dev), overflow=st.flag)
             hsplit.append(hsp)
         hs.append(hf)
-    out = ops.linear(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
+    if wide:
+        wh = ws[n - 1].detach()
+        whs = ops.split_pack(wh, st.shift_w[n - 1], st.flag, out=st.buf(("w", n - 1), wh.shape[0], wh.shape[1], dev))
+        out = ops.linear_f16x3(hsplit[-1], whs, bs[n - 1].detach(), out_f32=True, overflow=st.flag)
+    else:
+        out = ops.linear(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
     hs.append(out)
-    return out, (x_in, te, z1, a1, hs, hsplit)
+    return out, (x_in, te, z1, a1, hs, hsplit, xs)
 
 
 def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS):
     """`denoiser_backward` with the input-gradient products of layers n-2 .. 1 on clava_gemm_f16x3 (weight and bias
     gradients on the float32 kernels from the float32 copies every split product also writes)."""
-    x_in, te, z1, a1, hs, hsplit = saved
+    x_in, te, z1, a1, hs, hsplit, xs = saved
+    wide = xs is not None
     total = layout.total
     M = d_out.shape[0]
     dev = d_out.device
@@ -256,10 +279,18 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
             else:
                 param_grads(prefix, dy, inp)
 
-    # head (float32): parameter gradients and the gradient w.r.t. the last hidden pre-activation
-    param_grads_async(names[n - 1], d_out, hs[n - 2])
-    g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
-    gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
+    # head: parameter gradients and the gradient w.r.t. the last hidden pre-activation
+    if wide:
+        ds = ops.split_pack(d_out, st.shift_d, st.flag, out=st.buf(("d",), M, d_out.shape[1], dev))
+        param_grads_async(names[n - 1], d_out, hs[n - 2], ds, hsplit[n - 2])
+        wh = ws[n - 1].detach()
+        wht = ops.split_transpose(st.bufs[("w", n - 1)], out=st.buf(("wt", n - 1), wh.shape[1], wh.shape[0], dev))
+        gs, g = ops.linear_f16x3(ds, wht, act_out=hsplit[n - 2], slope=0.0, both=True, out_shift=st.shift_g[n - 2],
+                                 out=st.buf(("g", n - 2), M, wh.shape[1], dev), overflow=st.flag)
+    else:
+        param_grads_async(names[n - 1], d_out, hs[n - 2])
+        g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
+        gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
     for l in range(n - 2, 0, -1):
         param_grads_async(names[l], g, hs[l - 1], gs, hsplit[l - 1])
         w = ws[l].detach()
@@ -268,9 +299,15 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         if l - 1 >= 1:
             gs, g = ops.linear_f16x3(gs, wt, act_out=hsplit[l - 1], slope=0.0, both=True, out_shift=st.shift_g[l - 1],
                                      out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)
-        else:                                     # layer 0 = proj has no activation; only the float32 gradient is needed
+        elif wide:                                # layer 0 = proj has no activation; its wide weight gradient wants the planes
+            gs, g = ops.linear_f16x3(gs, wt, both=True, out_shift=st.shift_g[0], out=st.buf(("g", 0), M, w.shape[1], dev),
+                                     overflow=st.flag)
+        else:                                     # only the float32 gradient is needed
             g = ops.linear_f16x3(gs, wt, out_f32=True, overflow=st.flag)
-    param_grads_async("proj", g, x_in)
+    if wide:
+        param_grads_async("proj", g, x_in, gs, xs)
+    else:
+        param_grads_async("proj", g, x_in)
     param_grads_async("time_embed.2", g, a1)
     d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
     d_z1 = _silu_backward(z1, d_a1)

@@ -167,17 +167,20 @@ def test_weight_gradient_slabs_on_the_f16_matrix_cores(M, N, K, splits):
     assert relerr(got, f32) < 4e-6
 
 
-def test_split_training_backward_with_f16_weight_gradients_matches_the_float32_backward():
+@pytest.mark.parametrize("d_in", [6, 300])
+def test_split_training_backward_with_f16_weight_gradients_matches_the_float32_backward(d_in):
     """Batch 4096 (the configs' training batch): the whole backward into the gradient slabs, hidden-block weight gradients
-    on the split-f16 kernels, against the float32-kernel backward of the same step."""
+    on the split-f16 kernels, against the float32-kernel backward of the same step.  d_in = 300: the wide-table case, where
+    proj and head (forward, input gradient, weight gradient) run on the split-f16 kernels too."""
     from clavaddpm_amd import training as tr
     torch.manual_seed(0)
-    net = MLPDiffusion(6, 0, "none", {"d_layers": [256, 512, 512, 256], "dropout": 0.0}).to(DEV).train()
+    net = MLPDiffusion(d_in, 0, "none", {"d_layers": [256, 512, 512, 256], "dropout": 0.0}).to(DEV).train()
     B = 4096
     g = _gen(5)
-    x_in = torch.randn(B, 6, device=DEV, generator=g)
+    x_in = torch.randn(B, d_in, device=DEV, generator=g)
+    x_in[:, d_in // 2:] = torch.where(x_in[:, d_in // 2:] > 1.0, 0.0, -69.07755279541016)     # log-one-hot-like columns
     t = torch.randint(0, 1000, (B,), device=DEV, generator=g)
-    d_out = torch.randn(B, 6, device=DEV, generator=g) / B
+    d_out = torch.randn(B, d_in, device=DEV, generator=g) / B
     layout = tr.FlatLayout(net)
     slabs32 = torch.zeros((tr.GRAD_SPLITS, layout.total), device=DEV)
     out32, saved32 = tr.denoiser_forward(net, x_in, t)
@@ -185,7 +188,8 @@ def test_split_training_backward_with_f16_weight_gradients_matches_the_float32_b
     tr.denoiser_backward(net, saved32, d_out, layout, slabs32, collect=gs)
     st = tr.SplitTrainState()
     ws, _, _ = net.stack()
-    st.calibrate(ws, saved32[4], gs)
+    st.calibrate(ws, saved32[4], gs, x_in=x_in, d_out=d_out)
+    assert (d_in >= tr.WIDE_END_LAYERS) == (d_in == 300)
     res = {}
     for on in (False, True):        # same split-f16 forward / input-gradient chain; only the weight-gradient kernels differ
         tr.WGRAD_F16X3 = on
@@ -198,6 +202,7 @@ def test_split_training_backward_with_f16_weight_gradients_matches_the_float32_b
             tr.WGRAD_F16X3 = True
         res[on] = slabs16.double().sum(0)
     assert int(st.flag.item()) == 0
+    assert (saved16[6] is not None) == (d_in == 300)
     assert relerr(out16, out32) < 1e-5
     g32 = slabs32.double().sum(0)
     for name in layout.names:
