@@ -241,3 +241,68 @@ class HipGaussianMixture(_sk_gaussian_mixture()):
         w, m, pc = self._params_dev()
         _, _, labels = gmm_estep(self._device_x(np.asarray(X)), w, m, pc, want_resp=False, want_labels=True)
         return labels.cpu().numpy().astype(np.int64)
+
+
+def group_vote(cluster_labels, child_group_lengths, n_labels=None):
+    """Majority vote per parent group (`pipeline_modules.py:300-344`) on the device.
+
+    cluster_labels: the child rows' labels in `sorted_child_data` order (array-like of ints, or an int32 device tensor
+    straight from `gmm_estep` / `HipGaussianMixture.predict`); child_group_lengths: rows per parent group (all >= 1).
+    Returns (group_cluster_labels int64 [G], agree_rates float64 [G], group_assignment int64 [N, 1],
+    group_lengths_prob_dicts {label: {length: probability}}) - the four values the reference derives there."""
+    lengths = np.asarray(child_group_lengths, dtype=np.int64).reshape(-1)
+    G = len(lengths)
+    if G == 0 or int(lengths.min()) < 1:
+        # np.bincount of an empty group is empty and np.max of it raises in the reference (:306)
+        raise ValueError("group_vote: every group needs at least one row (zero-size array to reduction operation maximum)")
+    offsets = np.zeros(G + 1, dtype=np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    N = int(offsets[-1])
+    if torch.is_tensor(cluster_labels) and cluster_labels.is_cuda:
+        lab = cluster_labels.reshape(-1).to(torch.int32).contiguous()
+    else:
+        lab = torch.from_numpy(np.ascontiguousarray(np.asarray(cluster_labels).reshape(-1).astype(np.int32))).cuda()
+    if lab.numel() != N:
+        raise ValueError(f"group_vote: {lab.numel()} labels for groups of {N} rows")
+    dev = lab.device
+    if n_labels is None:
+        n_labels = int(lab.max().item()) + 1
+    max_len = int(lengths.max())
+    off_d = torch.from_numpy(offsets).to(dev)
+    g_lab = torch.empty(G, device=dev, dtype=torch.int32)
+    g_cnt = torch.empty(G, device=dev, dtype=torch.int32)
+    assign = torch.empty(N, device=dev, dtype=torch.int32)
+    # the (label, length) table is dense: fall back to counting the pairs on the host when it would be huge
+    dense = n_labels * (max_len + 1) <= (1 << 24)
+    hist = torch.zeros((n_labels, max_len + 1), device=dev, dtype=torch.int64) if dense else None
+    bad = torch.zeros(1, device=dev, dtype=torch.int32)
+    check(lib().clava_group_vote_i32(ptr(lab), ptr(off_d), c_ll(G), c_int(n_labels), ptr(g_lab), ptr(g_cnt), ptr(assign), ptr(hist),
+                                     c_int(max_len), ptr(bad), stream_ptr()), "clava_group_vote_i32")
+    if int(bad.item()) != 0:
+        raise ValueError("group_vote: a cluster label lies outside [0, n_labels)")
+    labels_h = g_lab.cpu().numpy().astype(np.int64)
+    agree = g_cnt.cpu().numpy().astype(np.int64) / lengths                  # most_common_label_count / group_length (:311)
+    prob = {}
+    if dense:
+        hh = hist.cpu().numpy()
+        first_seen = {}
+        for i, l in enumerate(labels_h.tolist()):                            # dict order of the reference: first appearance
+            if l not in first_seen:
+                first_seen[l] = i
+        for l in first_seen:
+            row = hh[l]
+            total = int(row.sum())
+            seen = {}
+            for ln in lengths[labels_h == l].tolist():
+                if ln not in seen:
+                    seen[ln] = int(row[ln]) / total
+            prob[l] = seen
+    else:
+        from collections import defaultdict
+        freq = {}
+        for l, ln in zip(labels_h.tolist(), lengths.tolist()):
+            freq.setdefault(l, defaultdict(int))[ln] += 1
+        for l, fd in freq.items():
+            tot = sum(fd.values())
+            prob[l] = {k: v / tot for k, v in fd.items()}
+    return labels_h, agree, assign.cpu().numpy().astype(np.int64).reshape(-1, 1), prob

@@ -399,6 +399,17 @@ int clava_kmpp_candidates_f64(const double* X, long long ldx, long long N, int d
 int clava_kmpp_pick_f64(const double* closest, long long N, const double* rand01, int T, double* workspace, long long* ids,
                         double* total, void* stream);
 
+/* ---- majority vote of child-row cluster labels per parent group ----------------------------------------
+ * The loop of pipeline_modules.py:300-321 and the (cluster, group length) frequency table of :332-340.  Group g owns the
+ * rows [group_offsets[g], group_offsets[g+1]) of labels (int32 in [0, n_labels), n_labels <= 1024; groups are
+ * contiguous, as `sorted_child_data` is).  group_label[g] = np.argmax(np.bincount(group)) (lowest label among the most
+ * frequent), top_count[g] = np.max(np.bincount(group)) (agree rate = top_count / length, divided by the host),
+ * assignment[i] = the label of row i's group (np.repeat, :321; may be NULL), size_hist[label * (max_len + 1) + length] += 1
+ * per group (int64, zeroed by the caller; may be NULL).  *bad_label_flag (device int, may be NULL) is set to 1 when a
+ * label falls outside [0, n_labels). */
+int clava_group_vote_i32(const int* labels, const long long* group_offsets, long long n_groups, int n_labels, int* group_label,
+                         int* top_count, int* assignment, long long* size_hist, int max_len, int* bad_label_flag, void* stream);
+
 /* ---- post-sampling decoding of numeric columns ------------------------------------------------------
  * out[N,d] = QuantileTransformer(output_distribution='normal').inverse_transform(x[N,d]) in float64: the
  * `dataset.num_transform.inverse_transform(...)` of pipeline_utils.py:913 (transformer built at lib/data.py:217-223;

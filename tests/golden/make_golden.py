@@ -558,9 +558,47 @@ def g12_postprocess():
          cols=np.array(cols), rounded=rounded)
 
 
+def g13_group_vote():
+    """The reference's own voting statements (pipeline_modules.py:297-344, the non-variational branch and the group-size
+    tables that follow it), compiled from its source text and run on synthetic labels / group lengths."""
+    from collections import defaultdict
+    path = "pipeline_modules.py"
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "pair_clustering_keep_id")
+    idx = next(i for i, n in enumerate(fn.body) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare)
+               and getattr(n.test.left, "id", "") == "clustering_method" and any(isinstance(m, ast.For) for m in n.orelse))
+    stmts = list(fn.body[idx].orelse)
+    for n in fn.body[idx + 1:]:
+        if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "child_df_with_cluster":
+            break
+        stmts.append(n)
+    freq_to_prob = _compile(_extract("pipeline_utils.py", "freq_to_prob"), {}, "pipeline_utils.py")
+    code = compile(ast.Module(body=stmts, type_ignores=[]), os.path.join(REF, path), "exec")
+    rng = np.random.RandomState(13)
+    out = {}
+    for tag, G, k, mean_len in (("a", 400, 7, 2.5), ("b", 150, 50, 40.0), ("c", 60, 3, 1.2)):
+        lengths = rng.poisson(mean_len, G) + 1
+        if tag == "b":
+            lengths[::17] = 300 + rng.randint(0, 50, len(lengths[::17]))      # a few long groups
+        N = int(lengths.sum())
+        home = np.repeat(rng.randint(0, k, G), lengths)
+        labels = np.where(rng.rand(N) < 0.6, home, rng.randint(0, k, N)).astype(np.int64)   # ties and split votes happen
+        ns = {"np": np, "defaultdict": defaultdict, "freq_to_prob": freq_to_prob, "cluster_labels": labels,
+              "child_group_lengths": lengths.astype(int), "sorted_child_data": np.zeros((N, 1)), "print": lambda *a, **k: None}
+        exec(code, ns)
+        prob = ns["group_lengths_prob_dicts"]
+        flat = np.array([[lab, ln, p] for lab, d in prob.items() for ln, p in d.items()], dtype=np.float64)
+        out.update({f"{tag}_labels": labels, f"{tag}_lengths": lengths.astype(np.int64),
+                    f"{tag}_group_labels": np.array(ns["group_cluster_labels"], dtype=np.int64),
+                    f"{tag}_agree": np.array(ns["agree_rates"], dtype=np.float64),
+                    f"{tag}_assignment": np.asarray(ns["group_assignment"], dtype=np.int64), f"{tag}_prob": flat,
+                    f"{tag}_mean_agree": np.array(ns["average_agree_rate"])})
+    save("g13_group_vote.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g13", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = {"g1": g1_schedule, "g2": g2_mlp, "g3": g3_gauss_step, "g4": g4_multinomial_step, "g5": g5_chains,
-           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training, "g11": g11_gmm_fit, "g12": g12_postprocess}
+           "g6": g6_loss, "g7": g7_classifier, "g8": g8_trainer, "g9": g9_gmm, "g10": g10_classifier_training, "g11": g11_gmm_fit, "g12": g12_postprocess, "g13": g13_group_vote}
     for w in which:
         fns[w]()

@@ -221,3 +221,49 @@ def test_hip_gaussian_mixture_fit_is_device_seeded_and_matches_sklearn():
     assert gm.n_iter_ == int(g["n_iter"])
     np.testing.assert_allclose(gm.means_, g["means"].numpy(), rtol=1e-8, atol=1e-10)
     assert np.array_equal(gm.predict(X), g["labels"].numpy())
+
+
+# ---------------------------------------------------------------------------------------------- majority vote (8f-2)
+def _prob_rows(prob):
+    return np.array([[lab, ln, p] for lab, d in prob.items() for ln, p in d.items()], dtype=np.float64)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g13_group_vote_matches_the_reference_statements(tag):
+    from conftest import golden, sub
+    from clavaddpm_amd.clustering import group_vote
+    g = sub(golden("g13_group_vote.npz"), tag + "_")
+    labels, agree, assign, prob = group_vote(g["labels"].numpy(), g["lengths"].numpy())
+    assert np.array_equal(labels, g["group_labels"].numpy())                 # winners exact, lowest label on ties
+    assert np.array_equal(agree, g["agree"].numpy())                         # same integer ratio in float64
+    assert np.array_equal(assign, g["assignment"].numpy())
+    assert np.array_equal(_prob_rows(prob), g["prob"].numpy())               # values and dict order
+    assert float(np.mean(agree)) == float(g["mean_agree"])
+
+
+def test_group_vote_large_table_against_the_oracle_and_device_labels():
+    from clavaddpm_amd.clustering import group_vote
+    from oracle import vote
+    rng = np.random.RandomState(3)
+    G, k = 200_000, 50
+    lengths = rng.poisson(2.5, G) + 1
+    lengths[::5003] = 5000                                                   # long groups: many rows per wavefront lane
+    N = int(lengths.sum())
+    labels = rng.randint(0, k, N).astype(np.int32)
+    ref = vote.group_vote(labels, lengths)
+    got = group_vote(torch.from_numpy(labels).cuda(), lengths, n_labels=k)   # labels as they leave the device E-step
+    for a, b in zip(got[:3], ref[:3]):
+        assert np.array_equal(a, b)
+    assert got[3] == ref[3] and list(got[3]) == list(ref[3])
+    # properties at full size: every winner's count is the maximum of its group, the assignment is constant per group
+    assert int(got[2].shape[0]) == N and float(got[1].max()) <= 1.0 and float(got[1].min()) > 0.0
+
+
+def test_group_vote_rejects_empty_groups_and_bad_labels():
+    from clavaddpm_amd.clustering import group_vote
+    with pytest.raises(ValueError):
+        group_vote(np.array([0, 1, 1]), np.array([2, 0, 1]))
+    with pytest.raises(ValueError):
+        group_vote(np.array([0, 1, 7]), np.array([2, 1]), n_labels=3)
+    with pytest.raises(ValueError):
+        group_vote(np.array([0, 1]), np.array([2, 1]))

@@ -5,6 +5,7 @@ checks are exact; where op grouping differs (hand-written AdamW restatement,
 numpy vs torch float64 transcendentals) the bound is stated at the check.
 """
 import numpy as np
+import pytest
 import torch
 
 import oracle
@@ -230,3 +231,20 @@ def test_g12_quantile_inverse_and_round_columns():
 
 def test_oracle_header_says_test_only():
     assert "TEST INFRASTRUCTURE ONLY" in oracle.__doc__
+
+
+def _prob_rows(prob):
+    return np.array([[lab, ln, p] for lab, d in prob.items() for ln, p in d.items()], dtype=np.float64)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g13_group_vote(tag):
+    """pipeline_modules.py:300-344 (majority vote per parent group, group-size distributions): bit-exact, dict order included."""
+    from oracle import vote
+    g = sub(golden("g13_group_vote.npz"), tag + "_")
+    labels, agree, assign, prob = vote.group_vote(g["labels"].numpy(), g["lengths"].numpy())
+    assert np.array_equal(labels, g["group_labels"].numpy())
+    assert np.array_equal(agree, g["agree"].numpy())
+    assert np.array_equal(assign, g["assignment"].numpy())
+    assert np.array_equal(_prob_rows(prob), g["prob"].numpy())
+    assert float(np.mean(agree)) == float(g["mean_agree"])
