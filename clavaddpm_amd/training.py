@@ -22,7 +22,7 @@ from .tab_ddpm.modules import timestep_embedding
 c_ll = ctypes.c_longlong
 WGRAD_F16X3 = os.environ.get("CLAVA_WGRAD_F16X3", "1") != "0"   # hidden-block weight gradients on the split-f16 kernels
 WIDE_END_LAYERS = int(os.environ.get("CLAVA_WIDE_END_LAYERS", "256"))   # D_in from which proj / head run split-f16 too (0 = never)
-GRAD_SPLITS = 8   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
+GRAD_SPLITS = int(os.environ.get("CLAVA_GRAD_SPLITS", "8"))   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
 
 def param_list(net):

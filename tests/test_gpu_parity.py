@@ -176,8 +176,9 @@ def test_sample_all_unconditional_mixed_properties():
     assert torch.equal(x, x2)                                           # same seed, same table
 
 
-@pytest.mark.parametrize("K", [[2, 8, 5], [16, 9, 3, 12], [32, 17, 2], [33, 64, 7], [256, 65, 130], [257, 1000, 4], [1025, 3, 1500]],
-                         ids=["g8", "g16", "g32", "g64", "regs256", "stream", "beyond1024"])
+@pytest.mark.parametrize("K", [[2, 8, 5], [16, 9, 3, 12], [32, 17, 2], [33, 64, 7], [256, 65, 130], [257, 1000, 4], [1025, 3, 1500],
+                               [2, 3] * 550],
+                         ids=["g8", "g16", "g32", "g64", "regs256", "stream", "beyond1024", "m1100_unstaged"])
 def test_multinomial_kernel_every_group_width_and_block_size(K):
     """Every code path of multinomial_step_kernel (8/16/32/64-lane groups, register-resident blocks up to 256 classes,
     streamed blocks, blocks beyond 1024 classes) x (reverse with and without log p, q_sample, t = 0 rows) against the
@@ -194,7 +195,7 @@ def test_multinomial_kernel_every_group_width_and_block_size(K):
     t[:7] = 0                                                  # the decoder rows (t == 0: log_EV = log_x0 branch)
     t[7:12] = T - 1
     u = torch.rand(B, sumK, generator=g)
-    ref_idx, _ = mn.p_sample(tb, logits, idx_t, t, u, K)
+    ref_idx, ref_lp = mn.p_sample(tb, logits, idx_t, t, u, K)
     new, lp = d.p_sample_index(logits.to(DEV), idx_t.to(DEV), t.to(DEV), u, return_log_prob=True)
     new2, _ = d.p_sample_index(logits.to(DEV), idx_t.to(DEV), t.to(DEV), u, return_log_prob=False)
     exact = mn.p_pred_exact_norm(tb, logits, mn.index_to_log_onehot(idx_t, K), t, K)
@@ -211,7 +212,11 @@ def test_multinomial_kernel_every_group_width_and_block_size(K):
         assert torch.equal(sc[:, off[f]:off[f + 1]].argmax(1)[safe[:, f]], new.cpu().long()[:, f][safe[:, f]])
     assert float(safe.double().mean()) > 0.99
     assert torch.equal(new.cpu()[safe], new2.cpu()[safe])
-    assert torch.equal(new.cpu().long()[safe], ref_idx[safe])
+    # the float32 restatement of the reference: its row-wide logcumsumexp normaliser (tab_ddpm/utils.py:151-166) degenerates
+    # on very wide rows (1100 blocks: -inf at t = 0, so log p = +inf and every draw is class 0); compare where it is finite
+    fin = torch.stack([torch.isfinite(ref_lp[:, off[f]:off[f + 1]]).all(1) for f in range(len(K))], 1)
+    assert float(fin.double().mean()) > 0.9
+    assert torch.equal(new.cpu().long()[safe & fin], ref_idx[safe & fin])
     uq = torch.rand(B, sumK, generator=g)
     q = d.q_sample_index(idx_t.to(DEV), t.to(DEV), uq)
     ref_q = mn.q_sample(tb, idx_t, t, uq, K)
