@@ -170,6 +170,8 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     const int Np = (g.N + 31) & ~31;
     const int m_lane = m0 + wm * (BM / WM) + lrow;
     bool ovf = false;
+    // float32 rows that start 16-byte aligned take vector stores (nq is a multiple of EW)
+    const bool f32_vec = g.out_f32 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f32) & 15) == 0;
 #pragma unroll
     for (int ip = 0; ip < EP; ++ip) {
         const int it = wn * TN + (EW == 8 ? 2 * ip : ip);    // n-subtile index inside the workgroup tile
@@ -230,9 +232,14 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
             }
             if (g.out_f32) {
                 float* cp = g.out_f32 + (long long)m * g.ldc + nq;
+                if (f32_vec && nq + EW <= g.N) {             // 16-byte stores: a lane's EW consecutive columns of one row
 #pragma unroll
-                for (int r = 0; r < EW; ++r)
-                    if (nq + r < g.N) cp[r] = v[r];
+                    for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(cp + r) = f32x4{v[r], v[r + 1], v[r + 2], v[r + 3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < EW; ++r)
+                        if (nq + r < g.N) cp[r] = v[r];
+                }
             }
         }
     }

@@ -222,7 +222,10 @@ def denoiser_forward_split(net, x_in, t, st):
     if wide:
         wh = ws[n - 1].detach()
         whs = ops.split_pack(wh, st.shift_w[n - 1], st.flag, out=st.buf(("w", n - 1), wh.shape[0], wh.shape[1], dev))
-        out = ops.linear_f16x3(hsplit[-1], whs, bs[n - 1].detach(), out_f32=True, overflow=st.flag)
+        # rows padded to a multiple of 4 floats: 16-byte stores in the epilogue whatever D_in is
+        d_pad = (wh.shape[0] + 3) // 4 * 4
+        out = torch.empty((B, d_pad), device=dev, dtype=torch.float32)[:, :wh.shape[0]]
+        ops.linear_f16x3(hsplit[-1], whs, bs[n - 1].detach(), out_f32=True, overflow=st.flag, out=out)
     else:
         out = ops.linear(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
     hs.append(out)
@@ -369,12 +372,13 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
     n = diffusion.num_numerical_features
     dev = model_out.device
     d_out = torch.empty((B, D), device=dev, dtype=torch.float32)
+    ld_out = model_out.stride(0)                  # the wide-table head writes rows padded to 16 bytes
     loss_multi = loss_gauss = None
     if n > 0:
         if diffusion.gaussian_loss_type != "mse":
             raise NotImplementedError("gaussian_loss_type='kl' is not implemented on the HIP path (every config uses 'mse')")
         rows = torch.empty(B, device=dev, dtype=torch.float32)
-        check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(D), ptr(noise), ptr(rows), ptr(d_out), c_int(D),
+        check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(ld_out), ptr(noise), ptr(rows), ptr(d_out), c_int(D),
                                              stream_ptr()), "clava_gauss_mse_loss_f32")
         loss_gauss = _device_sum(rows, 1.0 / B)
     if diffusion.has_cat:
@@ -385,7 +389,7 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
         sched = diffusion._c_schedule()
         pt = torch.tensor(1.0, dtype=torch.float32) / diffusion.num_timesteps        # ones_like(t).float() / T  (:592)
         check(lib().clava_multinomial_loss_f32(ctypes.byref(sched), c_int(B), c_int(m), c_int(sk), ptr(diffusion._offsets_i32),
-                                               ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(D), ptr(idx0), ptr(idxt), ptr(t),
+                                               ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(ld_out), ptr(idx0), ptr(idxt), ptr(t),
                                                c_float(float(pt)), ptr(terms), ptr(d_out[:, n:]), c_int(D), stream_ptr()),
               "clava_multinomial_loss_f32")
         loss_multi = _device_sum(terms, 1.0 / (m * B))

@@ -55,10 +55,12 @@ def measure(batch=4096, n_num=100, train_steps=60, chain_steps=100, T=1000, brea
     t0 = time.perf_counter()
     for _ in range(train_steps):
         tr._run_step(data, {"y": y})
+    t_enq = (time.perf_counter() - t0) / train_steps
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / train_steps
     flops = batch * 6.0 * (640 * (n_num + sk) + 4292608)
-    res["train"] = {"steps_per_s": round(1 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1)}
+    res["train"] = {"steps_per_s": round(1 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tflops": round(flops / dt / 1e12, 1),
+                    "host_enqueue_ms_per_step": round(t_enq * 1e3, 3)}
     if breakdown:
         L.clava_prof_enable(ctypes.c_int(8192))
         for _ in range(10):
