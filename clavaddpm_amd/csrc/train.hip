@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) colsum_slabs_kernel(const float* __restri
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
-        if (col < N) {                                           // N % 4 == 0 here: the whole float4 is in range
+        if (col < N) {                                           // the row holds the whole float4 (lddy >= round_up(N, 4))
             int r = r0 + q;
             for (; r + 32 < r1; r += 64) {
                 const float4 u = *reinterpret_cast<const float4*>(dy + (size_t)r * ld + col);
@@ -408,7 +408,9 @@ int clava_colsum_slabs_f32(const float* dy, int lddy, int M, int N, int splits, 
                            void* stream) {
     CLAVA_CHECK_ARG(dy && db_slabs && M > 0 && N > 0 && splits >= 1 && splits <= 64 && lddy >= N, "colsum_slabs: bad arguments");
     ProfScope prof(PROF_MISC, 0.0, 4.0 * M * N, (hipStream_t)stream);
-    const bool vec = (N % 4 == 0) && (lddy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+    // float4 loads need 16-byte aligned rows that hold the whole last float4 (columns beyond N inside the row are read and
+    // their sums discarded)
+    const bool vec = (lddy % 4 == 0) && lddy >= ((N + 3) & ~3) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
     if (vec)
         hipLaunchKernelGGL(colsum_slabs_kernel<true>, dim3((N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy, lddy, M, N,
                            splits, db_slabs, slab_stride);

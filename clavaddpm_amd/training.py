@@ -371,14 +371,15 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
     B, D = model_out.shape
     n = diffusion.num_numerical_features
     dev = model_out.device
-    d_out = torch.empty((B, D), device=dev, dtype=torch.float32)
+    # rows padded to 16 bytes (the pad columns are never read as data): float4 loads in the bias-gradient column sums
+    d_out = torch.empty((B, (D + 3) // 4 * 4), device=dev, dtype=torch.float32)[:, :D]
     ld_out = model_out.stride(0)                  # the wide-table head writes rows padded to 16 bytes
     loss_multi = loss_gauss = None
     if n > 0:
         if diffusion.gaussian_loss_type != "mse":
             raise NotImplementedError("gaussian_loss_type='kl' is not implemented on the HIP path (every config uses 'mse')")
         rows = torch.empty(B, device=dev, dtype=torch.float32)
-        check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(ld_out), ptr(noise), ptr(rows), ptr(d_out), c_int(D),
+        check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(ld_out), ptr(noise), ptr(rows), ptr(d_out), c_int(d_out.stride(0)),
                                              stream_ptr()), "clava_gauss_mse_loss_f32")
         loss_gauss = _device_sum(rows, 1.0 / B)
     if diffusion.has_cat:
@@ -390,7 +391,7 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
         pt = torch.tensor(1.0, dtype=torch.float32) / diffusion.num_timesteps        # ones_like(t).float() / T  (:592)
         check(lib().clava_multinomial_loss_f32(ctypes.byref(sched), c_int(B), c_int(m), c_int(sk), ptr(diffusion._offsets_i32),
                                                ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(ld_out), ptr(idx0), ptr(idxt), ptr(t),
-                                               c_float(float(pt)), ptr(terms), ptr(d_out[:, n:]), c_int(D), stream_ptr()),
+                                               c_float(float(pt)), ptr(terms), ptr(d_out[:, n:]), c_int(d_out.stride(0)), stream_ptr()),
               "clava_multinomial_loss_f32")
         loss_multi = _device_sum(terms, 1.0 / (m * B))
     return loss_multi, loss_gauss, d_out
