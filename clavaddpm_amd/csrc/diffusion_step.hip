@@ -14,6 +14,7 @@
 // Both are HBM-bound elementwise/reduction kernels.  Arithmetic follows the reference operation by operation,
 // including its dtype promotions (float64 chain state); the file is compiled with
 // -ffp-contract=off so that a*b + c*d rounds like the separate ATen ops do.
+#include <cstdlib>
 #include "rng.h"
 #include "step.h"
 #include "wave.h"
@@ -66,8 +67,8 @@ __global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
 constexpr int MAX_LDS_FEATURES = 1024;
 
 // One (row, feature) block per group of G lanes.  G = 64: one wavefront per block, classes lane-strided, the block's
-// size, offset and hot class in scalar registers.  G = 8 / 16 / 32 (picked when every K of the table fits): 8 / 4 / 2
-// blocks per wavefront, one class per lane.  Three streaming passes over the block's logits (maximum, softmax sum,
+// size, offset and hot class in scalar registers.  G = 8 / 16 / 32 (features of up to 8 / 16 / 32 classes): 8 / 4 / 2
+// blocks of one row per wavefront, one class per lane; the kernel orders the features by width in LDS.  Three streaming passes over the block's logits (maximum, softmax sum,
 // draw; the second and third hit L1/L2): HBM sees each logit once.
 //
 // The posterior's normaliser (sliced_logsumexp, utils.py:151-166) is a per-block constant that cannot move the arg-max;
@@ -77,21 +78,14 @@ constexpr int MAX_LDS_FEATURES = 1024;
 // (seed, global row * m + feature, step, stream, slot = 64 * (c / 256) + (c & 63)) for G = 64: a pure function of
 // (row, feature, class), whatever the grid or GPU count.
 template <int G, int MODE>
-__device__ __forceinline__ void multinomial_blocks(const MultiStepArgs& a, const int* s_off, const float* s_logk,
-                                                   const float* s_side, bool staged) {
+__device__ __forceinline__ void multinomial_block(const MultiStepArgs& a, const int* s_off, const float* s_logk,
+                                                  const float* s_side, bool staged, int row, int f, bool active) {
     constexpr int NW = (G == 64) ? 4 : 1;
     const int lane = threadIdx.x & (G - 1);
-    const long long n_pairs = (long long)a.B * a.m;
-    const long long group0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const long long n_groups = ((long long)gridDim.x * blockDim.x) / G;
-    if (group0 >= n_pairs) return;
-    // (row, feature) advance by n_groups pairs per iteration without a division in the loop
-    int row = (int)(group0 / a.m), f = (int)(group0 - (long long)row * a.m);
-    const int d_row = (int)(n_groups / a.m), d_f = (int)(n_groups - (long long)d_row * a.m);
     const unsigned stream_id = (MODE == MULTI_MODE_INIT) ? clava_rng::STREAM_INIT_CAT : clava_rng::STREAM_CAT;
     const bool side_staged = staged && !a.t_rows;
-    for (; row < a.B; row += d_row, f += d_f) {
-        if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
+    if (!active) return;              // whole G-lane groups leave together; the reductions below never cross a group
+    {
         int o = staged ? s_off[f] : a.offsets[f];
         int K = (staged ? s_off[f + 1] : a.offsets[f + 1]) - o;
         int hot = (MODE == MULTI_MODE_INIT) ? -1 : a.idx_in[(size_t)row * a.m + f];
@@ -238,38 +232,85 @@ __device__ __forceinline__ void multinomial_blocks(const MultiStepArgs& a, const
     }
 }
 
+// All (row, feature) blocks of the `n_feat` features listed in `perm`, 64 / G blocks of one row per wavefront work item.
+template <int G, int MODE>
+__device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const int* s_off, const float* s_logk, const float* s_side,
+                                                   const int* perm, int n_feat, long long wave0, long long n_waves) {
+    constexpr int PER = 64 / G;
+    const int W = (n_feat + PER - 1) / PER;                 // work items per row
+    if (W == 0) return;
+    // a stride coprime with W makes every wavefront walk through ALL the features of the bucket (their costs differ by
+    // up to 16x): the few wavefronts beyond the stride sit this bucket out
+    auto gcd = [](long long x, long long y) { while (y) { const long long r = x % y; x = y; y = r; } return x; };
+    while (n_waves > 1 && gcd(n_waves, W) != 1) --n_waves;
+    if (wave0 >= n_waves || wave0 >= (long long)a.B * W) return;
+    const int sub = (threadIdx.x & 63) / G;
+    int row = (int)(wave0 / W), w = (int)(wave0 - (long long)row * W);
+    const int d_row = (int)(n_waves / W), d_w = (int)(n_waves - (long long)d_row * W);
+    for (; row < a.B; row += d_row, w += d_w) {
+        if (w >= W) { w -= W; ++row; if (row >= a.B) break; }
+        const int fi = w * PER + sub;
+        multinomial_block<G, MODE>(a, s_off, s_logk, s_side, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
+    }
+}
+
+// Lane-group width of a feature: the smallest of 8 / 16 / 32 / 64 lanes that holds one class per lane (64 beyond).
+__device__ __forceinline__ int feature_bucket(int K) { return K <= 8 ? 0 : K <= 16 ? 1 : K <= 32 ? 2 : 3; }
+
 template <int MODE>
 __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) {
     __shared__ int s_off[MAX_LDS_FEATURES + 1];
     __shared__ float s_logk[MAX_LDS_FEATURES];
     __shared__ float s_side[2 * MAX_LDS_FEATURES];
-    __shared__ int s_maxk;
+    __shared__ int s_perm[MAX_LDS_FEATURES];       // features ordered by lane-group width
+    __shared__ int s_cnt[4], s_fill[4];
     const bool staged = a.m <= MAX_LDS_FEATURES;
-    if (threadIdx.x == 0) s_maxk = staged ? 0 : 64;
-    __syncthreads();
-    if (staged) {
-        int mk = 0;
-        for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
-        for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
-            const float logk = a.log_k[i];
-            s_logk[i] = logk;
-            mk = max(mk, a.offsets[i + 1] - a.offsets[i]);
-            if (MODE != MULTI_MODE_INIT && !a.t_rows) {     // one t for the whole launch: the side factors depend on the feature only
-                const int tp = (MODE == MULTI_MODE_QSAMPLE) ? a.t : max(a.t - 1, 0);
-                const float la = (MODE == MULTI_MODE_QSAMPLE) ? a.s.log_cumprod_alpha[tp] : a.s.log_alpha[a.t];
-                const float un = ((MODE == MULTI_MODE_QSAMPLE) ? a.s.log_1_min_cumprod_alpha[tp] : a.s.log_1_min_alpha[a.t]) - logk;
-                s_side[2 * i] = log_add_exp(0.f + la, un);
-                s_side[2 * i + 1] = log_add_exp(LOG_TINY + la, un);
-            }
+    const int wave_lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    if (!staged) {
+        // more features than the LDS tables hold: one wavefront per (row, feature) block, tables read from memory
+        const long long n_pairs = (long long)a.B * a.m;
+        if (wave0 >= n_pairs) return;
+        int row = (int)(wave0 / a.m), f = (int)(wave0 - (long long)row * a.m);
+        const int d_row = (int)(n_waves / a.m), d_f = (int)(n_waves - (long long)d_row * a.m);
+        for (; row < a.B; row += d_row, f += d_f) {
+            if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
+            multinomial_block<64, MODE>(a, s_off, s_logk, s_side, false, row, f, true);
         }
-        atomicMax(&s_maxk, mk);
+        return;
+    }
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = s_fill[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
+    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+        const float logk = a.log_k[i];
+        s_logk[i] = logk;
+        atomicAdd(&s_cnt[feature_bucket(a.offsets[i + 1] - a.offsets[i])], 1);
+        if (MODE != MULTI_MODE_INIT && !a.t_rows) {     // one t for the whole launch: the side factors depend on the feature only
+            const int tp = (MODE == MULTI_MODE_QSAMPLE) ? a.t : max(a.t - 1, 0);
+            const float la = (MODE == MULTI_MODE_QSAMPLE) ? a.s.log_cumprod_alpha[tp] : a.s.log_alpha[a.t];
+            const float un = ((MODE == MULTI_MODE_QSAMPLE) ? a.s.log_1_min_cumprod_alpha[tp] : a.s.log_1_min_alpha[a.t]) - logk;
+            s_side[2 * i] = log_add_exp(0.f + la, un);
+            s_side[2 * i + 1] = log_add_exp(LOG_TINY + la, un);
+        }
     }
     __syncthreads();
-    const int maxk = s_maxk;                       // the same in every workgroup: all of them see the same table
-    if (maxk <= 8) multinomial_blocks<8, MODE>(a, s_off, s_logk, s_side, staged);
-    else if (maxk <= 16) multinomial_blocks<16, MODE>(a, s_off, s_logk, s_side, staged);
-    else if (maxk <= 32) multinomial_blocks<32, MODE>(a, s_off, s_logk, s_side, staged);
-    else multinomial_blocks<64, MODE>(a, s_off, s_logk, s_side, staged);
+    // features grouped by lane-group width (their order inside a group does not matter: every draw is keyed by the
+    // feature, not by where it runs); a wavefront work item = one 64-lane block, or 2 / 4 / 8 narrower blocks of one row
+    const int n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
+    const int st1 = n0, st2 = n0 + n1, st3 = n0 + n1 + n2;
+    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+        const int bk = feature_bucket(s_off[i + 1] - s_off[i]);
+        const int pos = atomicAdd(&s_fill[bk], 1);
+        s_perm[(bk == 0 ? 0 : bk == 1 ? st1 : bk == 2 ? st2 : st3) + pos] = i;
+    }
+    __syncthreads();
+    // one loop per width (a single loop over mixed items would keep all four variants' registers live at once)
+    multinomial_bucket<8, MODE>(a, s_off, s_logk, s_side, s_perm, n0, wave0, n_waves);
+    multinomial_bucket<16, MODE>(a, s_off, s_logk, s_side, s_perm + st1, n1, wave0, n_waves);
+    multinomial_bucket<32, MODE>(a, s_off, s_logk, s_side, s_perm + st2, n2, wave0, n_waves);
+    multinomial_bucket<64, MODE>(a, s_off, s_logk, s_side, s_perm + st3, n3, wave0, n_waves);
 }
 
 // forward noising of the numeric columns, per-row t (gaussian_q_sample, :172-180)
@@ -350,7 +391,21 @@ int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
     CLAVA_CHECK_ARG(a.t_rows || (a.t >= 0 && a.t < a.s.T), "multinomial_step: t=%d outside [0,%d)", a.t, a.s.T);
     const long long pairs = (long long)a.B * a.m;
     const long long blocks = (pairs + 3) / 4;
-    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    // persistent grid: as many workgroups as the chip holds at once, so that every wavefront averages over many blocks
+    static int resident[64][3] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!resident[dev][a.mode]) {
+        const void* fn = a.mode == MULTI_MODE_REVERSE ? (const void*)multinomial_step_kernel<MULTI_MODE_REVERSE>
+                         : a.mode == MULTI_MODE_INIT  ? (const void*)multinomial_step_kernel<MULTI_MODE_INIT>
+                                                      : (const void*)multinomial_step_kernel<MULTI_MODE_QSAMPLE>;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const char* mult = getenv("CLAVA_STEP_GRID_MULT");
+        resident[dev][a.mode] = per_cu * cus * (mult ? atoi(mult) : 1);
+    }
+    const int grid = (int)(blocks < resident[dev][a.mode] ? blocks : resident[dev][a.mode]);
     // algorithmic bytes: logits 4/class in, log-one-hot 4/class out (+ injected uniforms 4/class), indices 4+4 per feature
     ProfScope prof(PROF_MULTI_STEP, 0.0, (double)a.B * ((double)a.sumK * ((a.logits ? 4 : 0) + (a.x_in ? 4 : 0) + (a.uniforms ? 4 : 0)) + 8.0 * a.m), stream);
     if (a.mode == MULTI_MODE_REVERSE) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_REVERSE>, dim3(grid), dim3(256), 0, stream, a);
