@@ -204,8 +204,11 @@ __global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
     const int lane = threadIdx.x & 63;
     const long long n_pairs = (long long)a.B * a.m;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-    if (wave0 >= n_pairs) return;
+    long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    // a stride coprime with m makes every wavefront walk through all the features (block costs differ by up to 16x)
+    auto gcd = [](long long x, long long y) { while (y) { const long long r = x % y; x = y; y = r; } return x; };
+    while (n_waves > 1 && gcd(n_waves, a.m) != 1) --n_waves;
+    if (wave0 >= n_waves || wave0 >= n_pairs) return;
     const int T = a.s.T;
     const float lca_T = a.s.log_cumprod_alpha[T - 1], l1mca_T = a.s.log_1_min_cumprod_alpha[T - 1];
     // (row, feature) advance by n_waves pairs per iteration without a division in the loop
@@ -391,8 +394,18 @@ int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int su
     a.s = *sched; a.B = B; a.m = m; a.sumK = sumK; a.logits = logits; a.ld_logits = ld_logits; a.idx0 = idx0; a.idxt = idxt;
     a.t_rows = t_rows; a.offsets = offsets; a.log_k = log_k; a.pt = pt; a.loss_terms = loss_terms; a.d_logits = d_logits; a.ld_d = ld_d;
     const long long blocks = ((long long)B * m + 3) / 4;
+    // persistent grid: as many workgroups as the chip holds at once, so that every wavefront averages over many blocks
+    static int resident[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!resident[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)multinomial_loss_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident[dev] = per_cu * cus;
+    }
     ProfScope prof(PROF_LOSS, 0.0, 8.0 * B * sumK, (hipStream_t)stream);
-    hipLaunchKernelGGL(multinomial_loss_kernel, dim3((int)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(multinomial_loss_kernel, dim3((int)(blocks < resident[dev] ? blocks : resident[dev])), dim3(256), 0, (hipStream_t)stream, a);
     CLAVA_CHECK_LAUNCH("clava_multinomial_loss_f32");
     return CLAVA_OK;
 }
