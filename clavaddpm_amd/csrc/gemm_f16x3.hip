@@ -347,6 +347,8 @@ const TileCfg kCfgs[] = {
     CLAVA_CFG(128, 160, 4, 2),   // 5
     CLAVA_CFG(128, 80, 8, 2),    // 6
     CLAVA_CFG(64, 128, 2, 2),    // 7: narrow outputs (heads, logits, the input gradient)
+    CLAVA_CFG(128, 80, 8, 4),    // 8, 9: four-stage twins of 6 and 7 for short contractions in a single round of tiles - the
+    CLAVA_CFG(64, 128, 2, 4),    //       whole k range is in flight at once (one exposed load latency instead of one per k block)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
@@ -355,7 +357,7 @@ bool g_attr_set[64][kNumCfgs] = {};   // per device: the LDS limit is a per-devi
 // Cost model, calibrated on MI355X with tools/bench_f16x3.py: a configuration's sustained rate on a full chip (TFLOP/s
 // algorithmic, K = 1024, M = 20000), the tiles of the most loaded CU run back to back, plus a fixed launch / prologue /
 // epilogue cost.  It reproduces the measured times of the sampling (M = 20000) and training (M = 4096) shapes to ~15 %.
-const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0};
+const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0, 0.0, 0.0};   // 8, 9: never picked by cost
 static_assert(sizeof(kRateTF) / sizeof(kRateTF[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one rate per configuration");
 
 int pick_cfg(int M, int N, int Kp) {
@@ -363,12 +365,19 @@ int pick_cfg(int M, int N, int Kp) {
     double best_cost = 1e300;
     for (int c = 0; c < kNumCfgs; ++c) {
         const int bn = kCfgs[c].bn, bm = kCfgs[c].bm;
+        if (kRateTF[c] <= 0.0) continue;
         if (bn > 64 && N <= bn / 2) continue;
         const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
         const double per_cu = (double)((tiles + 255) / 256);
         const double tile_us = 2.0 * bn * bm * (double)Kp / (kRateTF[c] * 1e6 / 256.0);
         const double cost = per_cu * tile_us + 5.0;
         if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    // latency-bound corner: at most one tile per CU and at most four k blocks per... stage set - take the four-stage twin
+    // (it holds 1 workgroup per CU, which only costs nothing when there is no second tile to run)
+    if ((best == 6 || best == 7) && Kp <= 256) {
+        const long long tiles = (long long)((M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((N + kCfgs[best].bn - 1) / kCfgs[best].bn);
+        if (tiles <= 256) best += 2;
     }
     return best;
 }
