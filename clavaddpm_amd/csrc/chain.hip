@@ -574,9 +574,12 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
             float* x_in = w.x_in + (size_t)r0 * D;
             char* x_split = rowp(w.x_split, split_pitch(D), r0);
             float* model_out = w.model_out + (size_t)r0 * D;
-            // ---- denoiser input as split rows
-            rc = clava_launch_split_pack(x_in, D, R, D, d->shift_in, x_split, split_pitch(D), overflow, G.den);
-            if (rc) return rc;
+            // ---- denoiser input as split rows: packed from the float32 image once; afterwards the step kernels write the
+            // next input's planes themselves (pad columns keep the zeros of this first pack)
+            if (s == 0) {
+                rc = clava_launch_split_pack(x_in, D, R, D, d->shift_in, x_split, split_pitch(D), overflow, G.den);
+                if (rc) return rc;
+            }
             if (G.cls != G.den) {
                 CLAVA_CHECK_HIP(hipEventRecord(pool->fork[gi], G.den), "sample_chain_f16x3: step fork");
                 CLAVA_CHECK_HIP(hipStreamWaitEvent(G.cls, pool->fork[gi], 0), "sample_chain_f16x3: step fork");
@@ -627,7 +630,9 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
                 g.x = x + (size_t)r0 * c->n_num;
                 g.grad = grad; g.ld_grad = c->n_num;
                 g.noise = c->noise ? c->noise + ((size_t)s * B + r0) * c->n_num : nullptr;
-                g.x_in = x_in; g.ld_xin = D;
+                g.x_in = nullptr; g.ld_xin = 0;
+                g.xs.base = x_split; g.xs.pitch = split_pitch(D); g.xs.scale = ldexpf(1.f, d->shift_in); g.xs.col0 = 0;
+                g.xs.overflow = overflow;
                 g.pred_xstart = nullptr;
                 g.t_rows = nullptr; g.t = t;
                 g.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
@@ -642,7 +647,9 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
                 q.logits = model_out + c->n_num; q.ld_logits = D;
                 q.idx_in = idx + (size_t)r0 * c->m; q.idx_out = idx + (size_t)r0 * c->m;
                 q.uniforms = c->uniforms ? c->uniforms + ((size_t)s * B + r0) * c->sumK : nullptr; q.ld_u = c->sumK;
-                q.x_in = x_in + c->n_num; q.ld_xin = D;
+                q.x_in = nullptr; q.ld_xin = 0;
+                q.xs.base = x_split; q.xs.pitch = split_pitch(D); q.xs.scale = ldexpf(1.f, d->shift_in); q.xs.col0 = c->n_num;
+                q.xs.overflow = overflow;
                 q.log_prob = nullptr; q.ld_lp = 0;
                 q.offsets = c->offsets; q.log_k = c->log_k;
                 q.t_rows = nullptr; q.t = t;

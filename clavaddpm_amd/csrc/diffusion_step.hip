@@ -23,6 +23,17 @@ namespace {
 
 constexpr float LOG_TINY = -69.07755279541016f;   // log(float32(1e-30)): value of log(clamp(onehot, 1e-30)) off the hot class
 
+// one element of a split row (split.h): both planes, 2-byte stores
+__device__ __forceinline__ void store_split(const SplitOut& o, int row, int col, float v) {
+    const float sc = v * o.scale;
+    if (!(fabsf(sc) <= 65504.f) && o.overflow) *o.overflow = 1;
+    const _Float16 hi = (_Float16)sc;
+    const _Float16 lo = (_Float16)(sc - (float)hi);
+    _Float16* p = reinterpret_cast<_Float16*>(o.base + (long long)row * o.pitch + (long long)(col >> 5) * 128) + (col & 31);
+    p[0] = hi;
+    p[32] = lo;
+}
+
 // ------------------------------------------------------------------------------------------------ Gaussian
 __global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
     const long long n = (long long)a.B * a.n_num;
@@ -60,6 +71,7 @@ __global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
         a.x[i] = out;
         if (a.pred_xstart) a.pred_xstart[i] = pred;
         if (a.x_in) a.x_in[(size_t)row * a.ld_xin + col] = (float)out;
+        if (a.xs.base) store_split(a.xs, row, a.xs.col0 + col, (float)out);
     }
 }
 
@@ -229,6 +241,8 @@ __device__ __forceinline__ void multinomial_block(const MultiStepArgs& a, const 
             float* xo = a.x_in + (size_t)row * a.ld_xin + o;
             for (int c = lane; c < K; c += G) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
         }
+        if (a.xs.base)
+            for (int c = lane; c < K; c += G) store_split(a.xs, row, a.xs.col0 + o + c, (c == best_c) ? 0.f : LOG_TINY);
     }
 }
 
@@ -407,7 +421,7 @@ int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
     }
     const int grid = (int)(blocks < resident[dev][a.mode] ? blocks : resident[dev][a.mode]);
     // algorithmic bytes: logits 4/class in, log-one-hot 4/class out (+ injected uniforms 4/class), indices 4+4 per feature
-    ProfScope prof(PROF_MULTI_STEP, 0.0, (double)a.B * ((double)a.sumK * ((a.logits ? 4 : 0) + (a.x_in ? 4 : 0) + (a.uniforms ? 4 : 0)) + 8.0 * a.m), stream);
+    ProfScope prof(PROF_MULTI_STEP, 0.0, (double)a.B * ((double)a.sumK * ((a.logits ? 4 : 0) + (a.x_in ? 4 : 0) + (a.xs.base ? 4 : 0) + (a.uniforms ? 4 : 0)) + 8.0 * a.m), stream);
     if (a.mode == MULTI_MODE_REVERSE) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_REVERSE>, dim3(grid), dim3(256), 0, stream, a);
     else if (a.mode == MULTI_MODE_INIT) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_INIT>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_QSAMPLE>, dim3(grid), dim3(256), 0, stream, a);

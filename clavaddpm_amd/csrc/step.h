@@ -5,6 +5,16 @@
 #include "clava_hip.h"
 typedef clava_schedule ScheduleDev;
 
+// Optional split-row destination of a step kernel's "next denoiser input" (csrc/split.h: hi = f16(v * scale),
+// lo = f16(v * scale - hi); 32-column blocks of 64 B hi | 64 B lo).  base == null: not written.
+struct SplitOut {
+    char* base = nullptr;
+    long long pitch = 0;
+    float scale = 1.f;
+    int col0 = 0;                      // column of the kernel's first column inside the denoiser input
+    int* overflow = nullptr;           // set to 1 when a scaled magnitude leaves the float16 range
+};
+
 struct GaussStepArgs {
     ScheduleDev s;
     int B, n_num;
@@ -13,6 +23,7 @@ struct GaussStepArgs {
     const float* grad; int ld_grad;    // guidance gradient or null
     const double* noise;               // [B, n_num] injected noise or null (Philox)
     float* x_in; int ld_xin;           // float(x_next) written here for the next denoiser call, or null
+    SplitOut xs;                       // ... and / or straight into the denoiser's split-row input (split.h format)
     double* pred_xstart;               // optional [B, n_num]
     const long long* t_rows; int t;    // per-row timestep, or null and one t for all rows
     int x_is_f32;                      // state currently holds float32 values: do the float32 arithmetic of the first step
@@ -30,6 +41,7 @@ struct MultiStepArgs {
     int* idx_out;                         // [B, m]
     const float* uniforms; int ld_u;      // [B, sumK] injected uniforms or null (Philox)
     float* x_in; int ld_xin;              // log-one-hot of idx_out for the next denoiser call, or null
+    SplitOut xs;                          // ... and / or straight into the denoiser's split-row input (columns col0 + offset + class)
     float* log_prob; int ld_lp;           // optional normalised log p(x_{t-1} | x_t) (REVERSE)
     const int* offsets;                   // device [m + 1]
     const float* log_k;                   // device [m]: log(K_f) in float32
