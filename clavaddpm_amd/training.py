@@ -180,6 +180,14 @@ class SplitTrainState:
         self.generation += 1
 
 
+def wgrad_split_ok(batch, splits=None):
+    """Whether the hidden-block weight gradients of a `batch`-row step run on the split-f16 kernels: every gradient slab
+    must be written each step, i.e. `splits` non-empty ranges of whole 32-row blocks."""
+    splits = GRAD_SPLITS if splits is None else splits
+    nkb = (batch + 31) // 32
+    return WGRAD_F16X3 and (splits - 1) * ((nkb + splits - 1) // splits) < nkb
+
+
 def denoiser_forward_split(net, x_in, t, st):
     """`denoiser_forward` with the hidden blocks (layers 1 .. n-2 of the stack) on clava_gemm_f16x3."""
     te = timestep_embedding(t, net.dim_t)
@@ -207,6 +215,7 @@ def denoiser_forward_split(net, x_in, t, st):
     hs = [h]
     hsplit = [ops.split_pack(h, st.shift_h[0], st.flag, out=st.buf(("h", 0), B, h.shape[1], dev))]
     wsp = []
+    planes_only = wgrad_split_ok(B)               # float32 activation copies only feed the float32 weight-gradient kernels
     for l in range(1, n - 1):
         w = ws[l].detach()
         wsp.append(ops.split_pack(w, st.shift_w[l], st.flag, out=st.buf(("w", l), w.shape[0], w.shape[1], dev)))
@@ -214,10 +223,14 @@ def denoiser_forward_split(net, x_in, t, st):
         if last and not wide:                     # the head reads float32: no split copy of the last hidden activation
             hf = ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", out_f32=True, overflow=st.flag)
             hsplit.append(None)
-        else:
+        elif last or not planes_only:
             hsp, hf = ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", both=True, out_shift=st.shift_h[l],
                                        out=st.buf(("h", l), B, w.shape[0], dev), overflow=st.flag)
             hsplit.append(hsp)
+        else:                                     # the backward only reads the planes (mask, transposed operand): no float32 copy
+            hsplit.append(ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", out_shift=st.shift_h[l],
+                                           out=st.buf(("h", l), B, w.shape[0], dev), overflow=st.flag))
+            hf = None
         hs.append(hf)
     if wide:
         wh = ws[n - 1].detach()
@@ -260,8 +273,7 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     side = st.side_stream(dev)
     keep = []
     # every slab must be written each step: the split product needs `splits` non-empty ranges of whole 32-row blocks
-    nkb = (M + 31) // 32
-    wgrad_split_ok = WGRAD_F16X3 and (splits - 1) * ((nkb + splits - 1) // splits) < nkb
+    split_wgrad = wgrad_split_ok(M, splits)
 
     def param_grads_async(prefix, dy, inp, dy_split=None, inp_split=None):
         ev = torch.cuda.Event()
@@ -269,7 +281,7 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         keep.append((dy, inp, dy_split, inp_split))
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            if dy_split is not None and inp_split is not None and wgrad_split_ok:
+            if dy_split is not None and inp_split is not None and split_wgrad:
                 # weight gradient on the f16 matrix cores: the batch is the contraction axis, so both operands are
                 # transposed (planes moved, not re-rounded); the bias gradient still sums the float32 copy
                 wi = layout.index[prefix + ".weight"]
