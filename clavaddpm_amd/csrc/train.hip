@@ -302,6 +302,34 @@ __global__ void __launch_bounds__(256) colsum_slabs_kernel(const float* __restri
     }
 }
 
+// The same sums over split rows (csrc/split.h): element = (hi + lo) * inv_scale, so the gradient planes the input-gradient
+// chain produces feed the bias gradients without a float32 copy.  32 columns = one 128-byte block of a row.
+typedef _Float16 colsum_h4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) colsum_slabs_split_kernel(const char* __restrict__ src, long long pitch, int M, int N, int splits,
+                                                                 float inv_scale, float* __restrict__ slabs, long long slab_stride) {
+    __shared__ float part[32][33];
+    const int cg = threadIdx.x & 7, q = threadIdx.x >> 3;       // column group (4 columns), row lane
+    const int rows_per = (M + splits - 1) / splits;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    const char* base = src + (long long)blockIdx.x * 128 + cg * 8;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + q; r < r1; r += 32) {
+        const colsum_h4 hi = *reinterpret_cast<const colsum_h4*>(base + (long long)r * pitch);
+        const colsum_h4 lo = *reinterpret_cast<const colsum_h4*>(base + (long long)r * pitch + 64);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] += (float)hi[c] + (float)lo[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[q][cg * 4 + c] = a[c];
+    __syncthreads();
+    if (threadIdx.x < 32 && blockIdx.x * 32 + threadIdx.x < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
+        slabs[(size_t)blockIdx.y * slab_stride + blockIdx.x * 32 + threadIdx.x] = t * inv_scale;
+    }
+}
+
 // out[i] = scale * sum_s slabs[s][i]
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S, long long stride, long long n,
                                                           float scale, float* __restrict__ out) {
@@ -431,6 +459,19 @@ int clava_colsum_slabs_f32(const float* dy, int lddy, int M, int N, int splits, 
         hipLaunchKernelGGL(colsum_slabs_kernel<false>, dim3((N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy, lddy, M, N,
                            splits, db_slabs, slab_stride);
     CLAVA_CHECK_LAUNCH("clava_colsum_slabs_f32");
+    return CLAVA_OK;
+}
+
+int clava_colsum_slabs_split(const void* dy_split, long long pitch, int shift, int M, int N, int splits, float* db_slabs,
+                             long long slab_stride, void* stream) {
+    CLAVA_CHECK_ARG(dy_split && db_slabs && M > 0 && N > 0 && splits >= 1 && splits <= 64, "colsum_slabs_split: bad arguments");
+    const int Np = (N + 31) & ~31;
+    CLAVA_CHECK_ARG(pitch >= 4LL * Np && pitch % 8 == 0 && (reinterpret_cast<uintptr_t>(dy_split) & 7) == 0 && shift >= -30 && shift <= 30,
+                    "colsum_slabs_split: pitch / alignment / shift");
+    ProfScope prof(PROF_MISC, 0.0, 4.0 * M * N, (hipStream_t)stream);
+    hipLaunchKernelGGL(colsum_slabs_split_kernel, dim3(Np / 32, splits), dim3(256), 0, (hipStream_t)stream, (const char*)dy_split, pitch, M,
+                       N, splits, ldexpf(1.f, -shift), db_slabs, slab_stride);
+    CLAVA_CHECK_LAUNCH("clava_colsum_slabs_split");
     return CLAVA_OK;
 }
 

@@ -289,8 +289,9 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
                 xt = ops.split_transpose(inp_split, out=st.buf(("T", prefix, "x"), inp_split.cols, inp_split.rows, dev))
                 ops.linear_wgrad_f16x3(dyt, xt, splits, slabs[:, layout.offsets[wi]:], total)
                 bi = layout.index[prefix + ".bias"]
-                check(lib().clava_colsum_slabs_f32(ptr(dy), c_int(dy.stride(0)), c_int(M), c_int(dy.shape[1]), c_int(splits),
-                                                   ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), stream_ptr()), "clava_colsum_slabs_f32")
+                check(lib().clava_colsum_slabs_split(ptr(dy_split.buf), c_ll(dy_split.pitch), c_int(dy_split.shift), c_int(M),
+                                                     c_int(dy_split.cols), c_int(splits), ptr(slabs[:, layout.offsets[bi]:]), c_ll(total),
+                                                     stream_ptr()), "clava_colsum_slabs_split")
             else:
                 param_grads(prefix, dy, inp)
 
@@ -311,7 +312,11 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         w = ws[l].detach()
         # W^T for the input gradient: the planes of the forward's packed weight, transposed (coalesced both ways)
         wt = ops.split_transpose(st.bufs[("w", l)], out=st.buf(("wt", l), w.shape[1], w.shape[0], dev))
-        if l - 1 >= 1:
+        if l - 1 >= 1 and split_wgrad:            # weight and bias gradients of layer l-1 read the planes: no float32 copy
+            gs = ops.linear_f16x3(gs, wt, act_out=hsplit[l - 1], slope=0.0, out_shift=st.shift_g[l - 1],
+                                  out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)
+            g = None
+        elif l - 1 >= 1:
             gs, g = ops.linear_f16x3(gs, wt, act_out=hsplit[l - 1], slope=0.0, both=True, out_shift=st.shift_g[l - 1],
                                      out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)
         elif wide:                                # layer 0 = proj has no activation; its wide weight gradient wants the planes

@@ -296,6 +296,10 @@ int clava_sum_f32(const float* v, long long n, float scale, float* out, void* st
  * clava_gemm_wgrad_f32). */
 int clava_colsum_slabs_f32(const float* dy, int lddy, int M, int N, int splits, float* db_slabs, long long slab_stride,
                            void* stream);
+/* the same column sums over split rows (dy as float16 planes with shift `shift`, pitch bytes per row): the bias gradient
+ * straight from the planes the split-f16 input-gradient chain produces, no float32 copy of dy. */
+int clava_colsum_slabs_split(const void* dy_split, long long pitch, int shift, int M, int N, int splits, float* db_slabs,
+                             long long slab_stride, void* stream);
 
 /* out[i] = scale * sum_s slabs[s*slab_stride + i], fixed order (flat gradient for autograd / the RCCL all-reduce). */
 int clava_slab_reduce_f32(const float* slabs, int splits, long long slab_stride, long long n, float scale, float* out,
