@@ -43,6 +43,33 @@ def gmm_estep(X, weights, means, precisions_chol, want_resp=True, want_labels=Tr
     return lpn, resp, labels
 
 
+def gmm_estep_noalloc(X, weights, means, precisions_chol, log_prob_norm, log_resp=None, labels=None):
+    """`clava_gmm_estep_noalloc_f64`: the E-step for callers that cannot allocate (graph capture, serving loops).  Every
+    tensor, outputs included, is the caller's (float64 device, contiguous; labels int32); the library's own tables live in
+    a static device array, so this call performs no device allocation at all - this wrapper allocates nothing either.
+    Limit: k <= 64 and 2*k*d + 3*k <= 65728 doubles.  Calls that overlap on one GPU race on that array."""
+    _lib.require_cuda(X, weights, means, precisions_chol, log_prob_norm, log_resp, labels)
+    for t in (X, weights, means, precisions_chol, log_prob_norm, log_resp):
+        if t is not None and (t.dtype != torch.float64 or not (t.dim() < 2 or t.stride(-1) == 1)):
+            raise _lib.ClavaHipError("gmm_estep_noalloc: contiguous float64 tensors expected")
+    for t in (weights, means, precisions_chol, log_prob_norm, log_resp, labels):
+        if t is not None and not t.is_contiguous():
+            raise _lib.ClavaHipError("gmm_estep_noalloc: contiguous tensors expected (this call makes no copies)")
+    N, d = X.shape
+    k = means.shape[0]
+    if labels is not None and labels.dtype != torch.int32:
+        raise _lib.ClavaHipError("gmm_estep_noalloc: labels must be int32")
+    if (log_prob_norm.numel() != N or (log_resp is not None and tuple(log_resp.shape) != (N, k))
+            or (labels is not None and labels.numel() != N) or tuple(precisions_chol.shape) != (k, d) or weights.numel() != k
+            or means.shape[1] != d):
+        raise _lib.ClavaHipError("gmm_estep_noalloc: output / parameter shapes do not match X [N,d] and means [k,d]")
+    if N:
+        check(lib().clava_gmm_estep_noalloc_f64(ptr(X), c_ll(X.stride(0)), c_ll(N), c_int(d), c_int(k), ptr(weights), ptr(means),
+                                                ptr(precisions_chol), ptr(log_prob_norm), ptr(log_resp), ptr(labels), stream_ptr()),
+              "clava_gmm_estep_noalloc_f64")
+    return log_prob_norm, log_resp, labels
+
+
 def gmm_mstep(X, log_resp, log_prob_norm=None, reg_covar=1e-6, workspace=None):
     """scikit-learn's diag M-step on the device.  X [N,d], log_resp [N,k], log_prob_norm [N] or None: float64 device
     tensors.  Returns one packed float64 device tensor [2 + k + 3*k*d] = (lower bound, bad-covariance flag, weights [k],

@@ -15,6 +15,8 @@
 // tiles (k <= 64).  X is read from HBM exactly once; the kernel is HBM-bound for k*d small and f64-MFMA-bound
 // otherwise.  The two products keep separate accumulators and are combined in scikit-learn's order.
 #include "common.h"
+#include <mutex>
+#include "clava_hip.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -531,11 +533,67 @@ void launch_mstep(const GmmMArgs& g, int G, int chunks, hipStream_t st) {
     hipLaunchKernelGGL((gmm_mstep_kernel<CT, (CT == 4 ? 2 : 4)>), dim3(G, chunks), dim3(256), 0, st, g);
 }
 
+// ---- scratch of the entry point that allocates nothing (clava_gmm_estep_noalloc_f64) -----------------------------------
+// The E-step's derived tables (mu*P, P: k x d each; three k-vectors) for up to KMAX components x NOALLOC_DMAX features
+// live in this file-scope device array instead of a caller workspace.  Every GPU the library runs on holds its own copy
+// (NOALLOC_DOUBLES * 8 = 513.5 KB) until the process ends.  The array's NAME is only a host-side stand-in: the device
+// address comes from hipGetSymbolAddress, once per device, and only that pointer is handed to kernels.
+constexpr int NOALLOC_DMAX = 512;
+constexpr long long NOALLOC_DOUBLES = 2LL * KMAX * NOALLOC_DMAX + 3LL * KMAX;
+static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// device pointer of `scratch` on the current device (looked up once per device, with that device current)
+int scratch_for_current_device(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        clava_set_error("gmm_estep_noalloc: hipGetDevice failed or device %d beyond %d: %s", dev, NOALLOC_MAX_DEVICES,
+                        hipGetErrorString(e));
+        return CLAVA_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double* p = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            (void)hipGetLastError();
+            clava_set_error("gmm_estep_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return CLAVA_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return CLAVA_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 long long clava_gmm_workspace_doubles(int k, int d) { return 2LL * k * d + 3LL * k; }
+
+long long clava_gmm_noalloc_max_doubles(void) { return NOALLOC_DOUBLES; }
+
+int clava_gmm_estep_noalloc_f64(const double* X, long long ldx, long long N, int d, int k, const double* weights,
+                                const double* means, const double* precisions_chol, double* log_prob_norm, double* log_resp,
+                                int* labels, void* stream) {
+    CLAVA_CHECK_ARG(d > 0 && k > 0, "gmm_estep_noalloc: bad shape d=%d k=%d", d, k);
+    if (k > KMAX || clava_gmm_workspace_doubles(k, d) > NOALLOC_DOUBLES) {
+        clava_set_error("gmm_estep_noalloc: k=%d, d=%d needs %lld doubles of tables, the static scratch holds %lld "
+                        "(k <= %d, 2*k*d + 3*k <= %lld); use clava_gmm_estep_f64 with a caller workspace",
+                        k, d, clava_gmm_workspace_doubles(k, d), NOALLOC_DOUBLES, KMAX, NOALLOC_DOUBLES);
+        return CLAVA_ERR_LIMIT;
+    }
+    double* ws = nullptr;
+    const int rc = scratch_for_current_device(&ws);
+    if (rc != CLAVA_OK) return rc;
+    // nothing in the scratch has to start at zero: gmm_prep_kernel rewrites every element the E-step kernel reads
+    return clava_gmm_estep_f64(X, ldx, N, d, k, weights, means, precisions_chol, ws, log_prob_norm, log_resp, labels, stream);
+}
 
 int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int k, const double* weights,
                         const double* means, const double* precisions_chol, double* workspace, double* log_prob_norm,

@@ -370,6 +370,18 @@ int clava_gmm_estep_f64(const double* X, long long ldx, long long N, int d, int 
                         const double* means, const double* precisions_chol, double* workspace, double* log_prob_norm,
                         double* log_resp, int* labels, void* stream);
 
+/* clava_gmm_estep_f64 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that may
+ * not call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it) and therefore cannot
+ * provide the workspace either.  Same arguments and results as clava_gmm_estep_f64 minus `workspace`: the derived
+ * parameter tables go to a static device array inside the library (clava_gmm_noalloc_max_doubles() doubles = 513.5 KB,
+ * held by every GPU the library runs on until the process ends).  Limit: k <= 64 and 2*k*d + 3*k <= that size
+ * (d <= 512 at k = 64); beyond it returns -3 with a message.  Calls no hipMalloc / hipFree or other allocating routine.
+ * All calls on one GPU share the array: calls that overlap on one GPU (two streams, two host threads) race. */
+long long clava_gmm_noalloc_max_doubles(void);
+int clava_gmm_estep_noalloc_f64(const double* X, long long ldx, long long N, int d, int k, const double* weights,
+                                const double* means, const double* precisions_chol, double* log_prob_norm, double* log_resp,
+                                int* labels, void* stream);
+
 /* M-step of the same mixture: scikit-learn's GaussianMixture._m_step for covariance_type='diag'
  * (sklearn/mixture/_gaussian_mixture.py `_estimate_gaussian_parameters`, `_estimate_gaussian_covariances_diag`,
  * `_compute_precision_cholesky`; called once per EM iteration from BaseMixture.fit_predict, _base.py) with
