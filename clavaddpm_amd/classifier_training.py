@@ -186,6 +186,7 @@ class ClassifierTrainer:
         self.betas, self.eps = (0.9, 0.999), 1e-8
         self.remove_first_col = remove_first_col
         self.eval_interval, self.log_interval = 5, 10
+        self.log_to_logger = False
         dev = next(classifier.parameters()).device if device is None else torch.device(device)
         _lib.require_cuda(next(classifier.parameters()))
         self.device = dev
@@ -342,6 +343,8 @@ class ClassifierTrainer:
                                         ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
                                         ctypes.c_double(self.weight_decay), c_ll(self.opt_step), ctypes.c_double(0.0), stream_ptr()),
               "clava_adamw_ema_f32")
+        from . import split_nets
+        split_nets.invalidate()      # parameters and BatchNorm statistics were rewritten through raw pointers
         return out
 
     def gradients(self):
@@ -391,6 +394,13 @@ class ClassifierTrainer:
                 if nv:
                     row += (vsums / nv).tolist()
                 self.history.append(row)
+                if self.log_to_logger:                             # the reference's table (`:786-790, 816-817`), on request
+                    from .tab_ddpm import logger
+                    logger.logkv("step", step)
+                    logger.logkv("samples", (step + 1) * len(x))
+                    for k, v in zip(("train_loss", "train_acc@1", "train_acc@5", "val_loss", "val_acc@1"), row[1:]):
+                        logger.logkv(k, v)
+                    logger.dumpkvs()
                 sums.zero_()
                 vsums.zero_()
                 n = nv = 0

@@ -181,11 +181,26 @@ class HipGaussianMixture(_sk_gaussian_mixture()):
         self.device = device
 
     _x_cache = (None, None)
+    _in_fit = False
+
+    def fit_predict(self, X, y=None):
+        """scikit-learn's EM driver (`fit` calls it too).  The device copy of the data matrix lives exactly as long as
+        this call: inside it scikit-learn passes one validated array to `_initialize_parameters`, `_e_step` and `_m_step`,
+        so one upload serves all EM iterations; nothing is cached across calls (an array mutated in place between `fit`
+        and `predict` is uploaded afresh)."""
+        self._in_fit = True
+        try:
+            return super().fit_predict(X, y)
+        finally:
+            self._in_fit = False
+            self._x_cache = (None, None)
 
     def _device_x(self, X):
         key, dev_x = self._x_cache
-        if key is not X:
-            dev_x = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(self.device)
+        if key is X and self._in_fit:
+            return dev_x
+        dev_x = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(self.device)
+        if self._in_fit:
             self._x_cache = (X, dev_x)
         return dev_x
 

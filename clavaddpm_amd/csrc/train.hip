@@ -62,8 +62,20 @@ struct LBlock {
     __device__ __forceinline__ float q1(int c) const { return c == hott ? q1_hot : q1_cold; }
     __device__ __forceinline__ float un_true(int c) const { return (c == hot0 ? evt_hot : evt_cold) + q1(c); }
     __device__ __forceinline__ float ev(float lstart) const {                  // q_pred(., t-1) or identity at t = 0
-        return t == 0 ? lstart : log_add_exp(lstart + lca_p, uni_p);
+        return t == 0 ? lstart : log_add_exp_acc(lstart + lca_p, uni_p);
     }
+};
+
+// sum_j exp(x_j - mx) of a block with the terms that ARE the maximum counted instead of added (each is exactly 1), so that
+// the normaliser mx + log(count + rest) keeps full relative accuracy when one class dominates (log_sum_counted, wave.h)
+struct CountedSum {
+    float rest = 0.f, n_max = 0.f;
+    __device__ __forceinline__ void add(float x, float mx) {
+        const float d = x - mx;
+        if (d == 0.f) n_max += 1.0f;
+        else rest += exp_nonpos(d);
+    }
+    __device__ __forceinline__ float log_total() const { return log_sum_counted(group_sum<64>(n_max), group_sum<64>(rest)); }
 };
 
 // One block of up to 64 * NCH classes held in registers (logit, ev(log-softmax), true-posterior weight / gradient):
@@ -82,11 +94,13 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
         }
     }
     b.mx = group_max<64>(m1);
-    float sm = 0.f;
+    {
+        CountedSum sm;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (j == 0 || j * 64 < K) sm += exp_nonpos(v[j] - b.mx);
-    b.lsum = log_pos(group_sum<64>(sm));
+        for (int j = 0; j < NCH; ++j)
+            if ((j == 0 || j * 64 < K) && lane + 64 * j < K) sm.add(v[j], b.mx);
+        b.lsum = sm.log_total();
+    }
     // normalisers of the model and true posteriors (direct per-block log-sum-exp)
     float mm = -INFINITY, mt = -INFINITY;
 #pragma unroll
@@ -99,15 +113,15 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
         }
     }
     mm = group_max<64>(mm); mt = group_max<64>(mt);
-    float sm_m = 0.f, sm_t = 0.f;
+    CountedSum sm_m, sm_t;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (j == 0 || j * 64 < K) {
             const int c = lane + 64 * j;
-            if (c < K) { sm_m += exp_nonpos((e[j] + b.q1(c)) - mm); sm_t += exp_nonpos(b.un_true(c) - mt); }
+            if (c < K) { sm_m.add(e[j] + b.q1(c), mm); sm_t.add(b.un_true(c), mt); }
         }
     }
-    const float lse_m = mm + log_pos(group_sum<64>(sm_m)), lse_t = mt + log_pos(group_sum<64>(sm_t));
+    const float lse_m = mm + sm_m.log_total(), lse_t = mt + sm_t.log_total();
     // loss terms: KL(true || model) (t > 0) or decoder NLL (t == 0) (:555-572), and the prior KL (:544-553)
     float W = 0.f, loss = 0.f, klp = 0.f;
 #pragma unroll
@@ -163,17 +177,19 @@ __device__ __forceinline__ void loss_block_streamed(const MLossArgs& a, LBlock& 
     float m1 = -INFINITY;
     for (int c = lane; c < K; c += 64) m1 = fmaxf(m1, b.lg[c]);
     b.mx = group_max<64>(m1);
-    float sm = 0.f;
-    for (int c = lane; c < K; c += 64) sm += exp_nonpos(b.lg[c] - b.mx);
-    b.lsum = log_pos(group_sum<64>(sm));
+    {
+        CountedSum sm;
+        for (int c = lane; c < K; c += 64) sm.add(b.lg[c], b.mx);
+        b.lsum = sm.log_total();
+    }
     auto lp = [&](int c) { return (b.lg[c] - b.mx) - b.lsum; };
     auto un_model = [&](int c) { return b.ev(lp(c)) + b.q1(c); };
     float mm = -INFINITY, mt = -INFINITY;
     for (int c = lane; c < K; c += 64) { mm = fmaxf(mm, un_model(c)); mt = fmaxf(mt, b.un_true(c)); }
     mm = group_max<64>(mm); mt = group_max<64>(mt);
-    float sm_m = 0.f, sm_t = 0.f;
-    for (int c = lane; c < K; c += 64) { sm_m += exp_nonpos(un_model(c) - mm); sm_t += exp_nonpos(b.un_true(c) - mt); }
-    const float lse_m = mm + log_pos(group_sum<64>(sm_m)), lse_t = mt + log_pos(group_sum<64>(sm_t));
+    CountedSum sm_m, sm_t;
+    for (int c = lane; c < K; c += 64) { sm_m.add(un_model(c), mm); sm_t.add(b.un_true(c), mt); }
+    const float lse_m = mm + sm_m.log_total(), lse_t = mt + sm_t.log_total();
     auto weight = [&](int c) { return (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : exp_nonpos(b.un_true(c) - lse_t); };
     float W = 0.f, loss = 0.f, klp = 0.f;
     for (int c = lane; c < K; c += 64) {
@@ -230,11 +246,11 @@ __global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
         b.lca_p = a.s.log_cumprod_alpha[tp];
         b.uni_p = a.s.log_1_min_cumprod_alpha[tp] - logk;
         const float la_t = a.s.log_alpha[b.t], uni_t = a.s.log_1_min_alpha[b.t] - logk;
-        b.q1_hot = log_add_exp(0.f + la_t, uni_t);
-        b.q1_cold = log_add_exp(LOG_TINY + la_t, uni_t);
+        b.q1_hot = log_add_exp_acc(0.f + la_t, uni_t);
+        b.q1_cold = log_add_exp_acc(LOG_TINY + la_t, uni_t);
         b.evt_hot = b.ev(0.f);
         b.evt_cold = b.ev(LOG_TINY);
-        const float lq_hot = log_add_exp(0.f + lca_T, l1mca_T - logk), lq_cold = log_add_exp(LOG_TINY + lca_T, l1mca_T - logk);
+        const float lq_hot = log_add_exp_acc(0.f + lca_T, l1mca_T - logk), lq_cold = log_add_exp_acc(LOG_TINY + lca_T, l1mca_T - logk);
         b.klp_hot = exp_nonpos(lq_hot) * (lq_hot + logk);
         b.klp_cold = exp_nonpos(lq_cold) * (lq_cold + logk);
         if (b.K <= 256) loss_block_cached<4>(a, b, lane, pair);

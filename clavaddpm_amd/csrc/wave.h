@@ -70,6 +70,29 @@ __device__ __forceinline__ float log_pos(float x) {
     pl = __builtin_fmaf(l, __int_as_float(0x3377d1cf), pl);
     return ph + pl;
 }
+// log(1 + x) for x >= 0, accurate RELATIVE to the result.  log_pos(1 + x) loses that near x = 0: the sum rounds to
+// float32 (6e-8 absolute on a result of size x) and the hardware log2 is only accurate in absolute terms around 1, so
+// a normaliser of a concentrated distribution (log of 1 + 4e-5) came out 2 % off - harmless for an arg-max, but the
+// training loss differentiates -w + exp(lm) with both terms within 1e-4 of one.  Below 1/4: 2 atanh(x / (2 + x)) by its
+// odd series (five terms, truncation < 1e-10 relative at z <= 1/9); above: the plain logarithm (result >= 0.22).
+__device__ __forceinline__ float log1p_acc(float x) {
+    if (x > 0.25f) return log_pos(1.0f + x);
+    const float z = x / (2.0f + x), z2 = z * z;
+    float p = __builtin_fmaf(z2, 1.0f / 9.0f, 1.0f / 7.0f);
+    p = __builtin_fmaf(z2, p, 0.2f);
+    p = __builtin_fmaf(z2, p, 1.0f / 3.0f);
+    p = __builtin_fmaf(z2 * z, p, z);
+    return 2.0f * p;
+}
+// log of (n_max + s): a log-sum-exp whose n_max largest terms (each exactly exp(0) = 1) were counted instead of summed and
+// whose other terms add up to s
+__device__ __forceinline__ float log_sum_counted(float n_max, float s) {
+    return n_max == 1.0f ? log1p_acc(s) : log_pos(n_max + s);
+}
+// log_add_exp with the accurate log1p (per-block scalars of the loss kernel, where the larger argument can be ~0)
+__device__ __forceinline__ float log_add_exp_acc(float x, float y) {
+    return fmaxf(x, y) + log1p_acc(exp_nonpos(-fabsf(x - y)));
+}
 // log_add_exp (tab_ddpm/utils.py:104-106): one of the two exponentials is exp(0) = 1 exactly
 __device__ __forceinline__ float log_add_exp(float x, float y) {
     const float m = fmaxf(x, y);

@@ -26,6 +26,12 @@ def _ld(t):
     return t.stride(0) if t.dim() == 2 else 0
 
 
+def _rs(t):
+    """Row stride of a 2-D tensor as a leading dimension.  torch reports an arbitrary stride(0) for a one-row tensor (a
+    [1, n] transpose of an [n, 1] weight has stride 1): any value >= the row length is equivalent there."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[-1])
+
+
 def linear(x, w, bias=None, act=None, rowadd=None, in_scale=None, in_shift=None, out=None):
     """act((x*in_scale+in_shift) @ w.T + bias + rowadd) via clava_gemm_bias_act_f32.
 
@@ -47,9 +53,9 @@ def linear(x, w, bias=None, act=None, rowadd=None, in_scale=None, in_shift=None,
             raise _lib.ClavaHipError("linear: rowadd width mismatch")
     if M == 0:
         return out
-    check(lib().clava_gemm_bias_act_f32(ptr(x), c_int(x.stride(0)), ptr(w), c_int(w.stride(0)), ptr(_f32c(bias, "bias")),
+    check(lib().clava_gemm_bias_act_f32(ptr(x), c_int(_rs(x)), ptr(w), c_int(_rs(w)), ptr(_f32c(bias, "bias")),
                                         ptr(rowadd), c_int(ldr), ptr(_f32c(in_scale, "in_scale")),
-                                        ptr(_f32c(in_shift, "in_shift")), ptr(out), c_int(out.stride(0)), c_int(M),
+                                        ptr(_f32c(in_shift, "in_shift")), ptr(out), c_int(_rs(out)), c_int(M),
                                         c_int(N), c_int(K), c_int(_ACT[act]), stream_ptr()), "clava_gemm_bias_act_f32")
     return out
 
@@ -66,9 +72,9 @@ def linear_dgrad(dy, w, act_out=None, slope=0.0, col_scale=None, alpha=1.0, out=
         out = torch.empty((M, K), device=dy.device, dtype=torch.float32)
     if M == 0:
         return out
-    check(lib().clava_gemm_dgrad_f32(ptr(dy), c_int(dy.stride(0)), ptr(w), c_int(w.stride(0)), ptr(_f32c(act_out, "act_out")),
-                                     c_int(act_out.stride(0) if act_out is not None else 0), c_float(slope),
-                                     ptr(_f32c(col_scale, "col_scale")), c_float(alpha), ptr(out), c_int(out.stride(0)),
+    check(lib().clava_gemm_dgrad_f32(ptr(dy), c_int(_rs(dy)), ptr(w), c_int(_rs(w)), ptr(_f32c(act_out, "act_out")),
+                                     c_int(_rs(act_out) if act_out is not None else 0), c_float(slope),
+                                     ptr(_f32c(col_scale, "col_scale")), c_float(alpha), ptr(out), c_int(_rs(out)),
                                      c_int(M), c_int(N), c_int(K), stream_ptr()), "clava_gemm_dgrad_f32")
     return out
 
@@ -86,7 +92,7 @@ def linear_wgrad(dy, x, splits=1, out=None, slab_stride=None):
         out = torch.empty((splits, N, K), device=dy.device, dtype=torch.float32)
     if slab_stride is None:
         slab_stride = N * K
-    check(lib().clava_gemm_wgrad_f32(ptr(dy), c_int(dy.stride(0)), ptr(x), c_int(x.stride(0)), ptr(out), c_int(K),
+    check(lib().clava_gemm_wgrad_f32(ptr(dy), c_int(_rs(dy)), ptr(x), c_int(_rs(x)), ptr(out), c_int(K),
                                      _lib.c_long(slab_stride), c_int(M), c_int(N), c_int(K), c_int(splits), stream_ptr()),
           "clava_gemm_wgrad_f32")
     return out
@@ -127,7 +133,7 @@ def split_pack(x, shift=0, overflow=None, out=None):
             raise _lib.ClavaHipError("split_pack: `out` has another shape")
         out.shift = shift
     if rows:
-        check(lib().clava_split_pack_f32(ptr(x), _lib.c_long(x.stride(0)), _lib.c_long(rows), c_int(cols), c_int(shift),
+        check(lib().clava_split_pack_f32(ptr(x), _lib.c_long(_rs(x)), _lib.c_long(rows), c_int(cols), c_int(shift),
                                          ptr(out.buf), _lib.c_long(out.pitch), ptr(overflow), stream_ptr()), "clava_split_pack_f32")
     return out
 
@@ -144,7 +150,7 @@ def split_pack_transposed(x, shift=0, overflow=None, out=None):
             raise _lib.ClavaHipError("split_pack_transposed: `out` has another shape")
         out.shift = shift
     if rows:
-        check(lib().clava_split_pack_transposed_f32(ptr(x), _lib.c_long(x.stride(0)), _lib.c_long(rows), c_int(cols), c_int(shift),
+        check(lib().clava_split_pack_transposed_f32(ptr(x), _lib.c_long(_rs(x)), _lib.c_long(rows), c_int(cols), c_int(shift),
                                                     ptr(out.buf), _lib.c_long(out.pitch), ptr(overflow), stream_ptr()),
               "clava_split_pack_transposed_f32")
     return out
@@ -183,7 +189,7 @@ def split_unpack(s):
     out = torch.empty((s.rows, s.cols), device=s.buf.device, dtype=torch.float32)
     if s.rows:
         check(lib().clava_split_unpack_f32(ptr(s.buf), _lib.c_long(s.pitch), _lib.c_long(s.rows), c_int(s.cols), c_int(s.shift),
-                                           ptr(out), _lib.c_long(out.stride(0)), stream_ptr()), "clava_split_unpack_f32")
+                                           ptr(out), _lib.c_long(_rs(out)), stream_ptr()), "clava_split_unpack_f32")
     return out
 
 
@@ -215,7 +221,7 @@ def linear_f16x3(x, w, bias=None, act=None, rowadd=None, act_out=None, slope=0.0
                                  ptr(y_split.buf) if y_split is not None else None,
                                  _lib.c_long(y_split.pitch if y_split is not None else 0),
                                  c_int(y_split.shift if y_split is not None else 0), ptr(y_f32),
-                                 c_int(y_f32.stride(0) if y_f32 is not None else 0), c_int(M), c_int(N), c_int(K), ptr(overflow),
+                                 c_int(_rs(y_f32) if y_f32 is not None else 0), c_int(M), c_int(N), c_int(K), ptr(overflow),
                                  c_int(tile_config), stream_ptr()), "clava_gemm_f16x3")
     if both:
         return y_split, y_f32

@@ -70,7 +70,41 @@ class Classifier(nn.Module):
                                       "forward, the backward and AdamW on the HIP library")
         emb = time_embed_forward(self.time_embed, timesteps, self.dim_t)
         ws, bs, acts, sc, sh = self.stack()
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the reference's guidance closure differentiates the logits w.r.t. the input (pipeline_utils.py:856-864:
+            # x_in.requires_grad_(True), torch.autograd.grad(selected.sum(), x_in)); weights are constants in eval mode
+            return _ClassifierInputGradFn.apply(x, emb, [w.detach() for w in ws], [b.detach() for b in bs], acts, sc, sh)
         return run_stack(ws, bs, acts, x.float(), rowadd0=emb, bn_scale=sc, bn_shift=sh)[-1]
+
+
+class _ClassifierInputGradFn(torch.autograd.Function):
+    """logits = classifier(x, t) in eval mode with d(logits)/d(x) for autograd: forward = clava_net_forward_f32 (keeps the
+    per-layer outputs), backward = clava_net_input_grad_f32.  Only the input is differentiable (guidance never updates the
+    classifier); this is what lets the reference's `cond_fn` closure run unchanged on this class."""
+
+    @staticmethod
+    def forward(ctx, x, emb, ws, bs, acts, sc, sh):
+        xin = x.detach().float().contiguous()
+        outs = run_stack(ws, bs, acts, xin, rowadd0=emb, bn_scale=sc, bn_shift=sh)
+        ctx.net_args = (ws, bs, acts, sc, sh)
+        ctx.outs = outs
+        ctx.x_dtype = x.dtype
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ws, bs, acts, sc, sh = ctx.net_args
+        outs = ctx.outs
+        B = dlogits.shape[0]
+        dl = dlogits.detach().float().contiguous()
+        net, keep = _native.make_net(ws, bs, acts, sc, sh)
+        grads = [torch.empty((B, w.shape[1]), device=dl.device, dtype=torch.float32) for w in ws]
+        if B:
+            check(lib().clava_net_input_grad_f32(ctypes.byref(net), c_int(B), _native.void_array(outs), ptr(dl),
+                                                 _native.void_array(grads), c_float(1.0), stream_ptr()),
+                  "clava_net_input_grad_f32")
+        del keep
+        return grads[0].to(ctx.x_dtype), None, None, None, None, None, None
 
 
 def logsoftmax_select_grad(logits, y):

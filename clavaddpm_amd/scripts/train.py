@@ -47,6 +47,13 @@ class Trainer:
         self._use_graph = os.environ.get("CLAVA_TRAIN_GRAPH", "1") != "0"
 
         net = diffusion._denoise_fn
+        # this loop calls the HIP forward / backward directly, so MLPDiffusion.forward's own guards never run: refuse
+        # here what the fused step does not compute instead of training silently without it
+        if any(b.dropout.p > 0 for b in net.mlp.blocks):
+            raise NotImplementedError("dropout > 0 is not implemented on the HIP training path (every ClavaDDPM config uses 0.0)")
+        if getattr(net, "is_y_cond", "none") == "embedding" or hasattr(net, "label_emb"):
+            raise NotImplementedError("is_y_cond='embedding' (label_emb) has no HIP training path (ClavaDDPM trains with 'none', "
+                                      "pipeline_modules.py:52)")
         self.layout = _tr.FlatLayout(net)
         dev = next(net.parameters()).device
         total = self.layout.total
@@ -178,6 +185,8 @@ class Trainer:
                                         ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
                                         ctypes.c_double(self.weight_decay), c_ll(self.opt_step), ctypes.c_double(self.ema_rate),
                                         stream_ptr()), "clava_adamw_ema_f32")
+        from .. import split_nets
+        split_nets.invalidate()      # the kernel above rewrote the parameters through raw pointers: packed copies are stale
         zero = torch.zeros((), device=x.device)
         return (loss_multi if loss_multi is not None else zero), (loss_gauss if loss_gauss is not None else zero)
 

@@ -164,25 +164,71 @@ class SplitNet:
 
 
 _cache = {}
+_generation = 0          # bumped by everything that rewrites weights through raw device pointers (see `invalidate`)
+_POS = {}
 
 
-def _signature(tensors):
-    """Value fingerprint of the weights (the optimizer kernel updates parameters through raw pointers, which torch's
-    version counters do not see)."""
-    parts = [t.detach().double().sum() + (t.detach().double() ** 2).sum() * 3.0 for t in tensors if t is not None]
+def invalidate():
+    """Declare every cached SplitNet possibly stale.  Called by the kernels' callers that update parameters or BatchNorm
+    statistics through raw pointers (`Trainer._optimizer_step`, `ClassifierTrainer.step`), which torch's version counters
+    do not see; call it yourself after writing weights through `.data` in place."""
+    global _generation
+    _generation += 1
+
+
+def _pos_weights(n, device):
+    key = (str(device), n)
+    w = _POS.get(key)
+    if w is None:
+        if len(_POS) >= 64:
+            _POS.clear()
+        w = (torch.arange(n, device=device, dtype=torch.int64) * 0x9E3779B1 + 0x7F4A7C15) | 1
+        _POS[key] = w
+    return w
+
+
+def _fingerprint(tensors):
+    """Exact, position-weighted fingerprint of the weights' BIT PATTERNS: sum_i bits_i * odd_weight(i) in wrapping
+    int64 arithmetic, tensors combined with distinct odd multipliers.  Unlike a sum of values / squares it changes when
+    two values swap places or move between tensors, and there is no floating-point cancellation."""
+    parts = []
+    for j, t in enumerate(tensors):
+        if t is None or t.numel() == 0:
+            continue
+        flat = t.detach().reshape(-1).contiguous()
+        bits = flat.view(torch.int32 if flat.element_size() % 4 == 0 else torch.uint8).to(torch.int64)
+        parts.append((bits * _pos_weights(bits.numel(), t.device)).sum() * (2 * j + 1))
     return torch.stack(parts).sum()
 
 
-def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False):
-    """SplitNet for these weights, cached until any weight value changes."""
-    tensors = list(ws) + list(bs) + list(sc or []) + list(sh or [])
-    key = tuple((t.data_ptr(), tuple(t.shape)) for t in list(ws) + list(bs)) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1])
-    sig = _signature(tensors + [emb_table])
+def _versions(tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
+def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False, watch=None):
+    """SplitNet for these weights, cached until a weight changes.
+
+    `watch` = every tensor the prepared network depends on (the module's parameters and BatchNorm buffers, the
+    time-embedding layers included); default: ws + bs.  A cache entry is reused without any device work while (a) no
+    raw-pointer writer has run since (`invalidate()` generation) and (b) torch's version counter of every watched
+    tensor is unchanged; otherwise the exact fingerprint decides (one small reduction + one host sync), and the entry
+    is rebuilt if it differs.  Entries keep their tensors alive, so a cached device address cannot be handed to another
+    tensor by the allocator while the entry exists."""
+    watch = [t.detach() for t in (watch if watch is not None else list(ws) + list(bs)) if t is not None]
+    key = tuple((t.data_ptr(), tuple(t.shape)) for t in watch) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1])
     hit = _cache.get(key)
-    if hit is not None and bool(hit[1] == sig):
-        return hit[0]
+    vers = _versions(watch)
+    if hit is not None:
+        if hit["gen"] == _generation and hit["vers"] == vers:
+            return hit["net"]
+        sig = _fingerprint(watch)
+        if bool(hit["sig"] == sig):
+            hit["gen"], hit["vers"] = _generation, vers
+            return hit["net"]
+    else:
+        sig = _fingerprint(watch)
     net = SplitNet(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal, need_grad)
     if key not in _cache and len(_cache) >= 8:
         _cache.pop(next(iter(_cache)))
-    _cache[key] = (net, sig, list(ws) + list(bs))
+    _cache[key] = {"net": net, "sig": sig, "gen": _generation, "vers": vers, "keep": watch}
     return net

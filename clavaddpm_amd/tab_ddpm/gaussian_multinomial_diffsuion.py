@@ -266,7 +266,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         offs = self._offsets_i32.cpu().tolist() if self.has_cat else None
         x_cal, cal_max = split_nets.calibration_input(self.num_numerical_features, offs, dev)
         shift_in = split_nets.shift_for(cal_max, split_nets.IN_TARGET_LOG2)
-        den = split_nets.prepare(ws, bs, acts, None, None, den_emb, x_cal, shift_in)
+        den = split_nets.prepare(ws, bs, acts, None, None, den_emb, x_cal, shift_in, watch=list(self._denoise_fn.parameters()))
         cls = None
         if guidance is not None:
             clf = guidance.classifier
@@ -274,7 +274,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             n_cls = cw[-1].shape[0]
             y_cal = (torch.arange(split_nets.CAL_ROWS, device=dev) % n_cls).to(torch.int32)
             cls = split_nets.prepare([w.detach() for w in cw], [b.detach() for b in cb], cacts, sc, sh, cls_emb, x_cal, shift_in,
-                                     y_cal=y_cal, need_grad=True)
+                                     y_cal=y_cal, need_grad=True, watch=list(clf.parameters()) + list(clf.buffers()))
         x0 = x.clone()
         idx0 = idx.clone() if idx is not None else None
         flag = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -346,7 +346,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             return self._finish(x, idx), out_dict
         from ..pipeline_utils import ClassifierGuidance
         if cond_fn is None or isinstance(cond_fn, ClassifierGuidance):
-            keep = self._run_chain(x, idx, cond_fn, out_dict['y'], noise, seed, row_offset, n_steps)
+            labels = self._guidance_labels(model_kwargs, b) if cond_fn is not None else out_dict['y']
+            keep = self._run_chain(x, idx, cond_fn, labels, noise, seed, row_offset, n_steps)
         else:
             keep = self._run_chain_python_guidance(x, cond_fn, model_kwargs or {}, noise, seed, row_offset, n_steps)
         sample = self._finish(x, idx)   # .cpu() synchronises; `keep` may go now
@@ -369,7 +370,11 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         if cond_fn is None or isinstance(cond_fn, ClassifierGuidance):
             if cond_fn is not None and self.has_cat:
                 raise NotImplementedError("guidance is Gaussian-only")
-            keep = self._run_chain(x, idx, cond_fn, out_dict['y'], noise, seed, row_offset, n_steps)
+            # the guidance target is model_kwargs['y'] (`cond_fn(x, t, **model_kwargs)`, :315-328), NOT the label drawn
+            # from y_dist above: `conditional_sampling` (pipeline_utils.py:1001-1012) passes its own `classes` there and
+            # records them as the rows' clusters
+            labels = self._guidance_labels(model_kwargs, b) if cond_fn is not None else out_dict['y']
+            keep = self._run_chain(x, idx, cond_fn, labels, noise, seed, row_offset, n_steps)
         else:
             if self.has_cat:
                 raise NotImplementedError("a Python cond_fn with categorical columns is not supported")
@@ -377,6 +382,23 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         sample = self._finish(x, idx)
         del keep
         return sample, out_dict
+
+    def _guidance_labels(self, model_kwargs, b):
+        """The fused chain's guidance target: `model_kwargs['y']`, exactly what the reference hands to its closure
+        (`cond_fn(x, t, **model_kwargs)`, `:315-328`; the closure asserts `y is not None`, pipeline_utils.py:855)."""
+        kw = model_kwargs or {}
+        extra = set(kw) - {"y", "remove_first_col"}
+        if extra:
+            raise TypeError(f"cond_fn() got an unexpected keyword argument {sorted(extra)[0]!r}")
+        if kw.get("remove_first_col", False):
+            raise NotImplementedError("remove_first_col=True is not wired into the fused guided chain (ClavaDDPM never "
+                                      "passes it); wrap the guidance in a plain Python cond_fn to use it")
+        y = kw.get("y", None)
+        assert y is not None                                  # the reference closure's own assertion
+        y = torch.as_tensor(y)
+        if y.numel() != b:
+            raise ValueError(f"model_kwargs['y'] holds {y.numel()} labels for {b} rows")
+        return y.reshape(-1).long().to(self._device())
 
     def _run_chain_python_guidance(self, x, cond_fn, model_kwargs, noise, seed, row_offset, n_steps=None):
         """Per-step loop for an arbitrary Python `cond_fn(x, t, **model_kwargs)` (the reference's closure contract):

@@ -1,32 +1,36 @@
-"""Timestep samplers for classifier training (`tab_ddpm/resample.py:10-69` of the reference).
+"""Timestep sampler for classifier training: the `'uniform'` sampler ClavaDDPM builds at `pipeline_utils.py:779-781`
+(reference `tab_ddpm/resample.py`, whose loss-aware samplers and their dead `dist.all_gather` calls are not provided).
 
-Only the sampler ClavaDDPM uses is provided: `create_named_schedule_sampler('uniform', diffusion)`
-(`pipeline_utils.py:779-781`).  `sample` keeps the reference's host-side draw (`np.random.choice`, so a seeded NumPy
-generator reproduces the reference's timesteps) and returns `(timesteps long[B], weights float[B])` on `device`;
-`ClassifierTrainer` draws on the device instead unless a sampler is handed to it.
+Contract kept: `create_named_schedule_sampler('uniform', diffusion).sample(batch_size, device)` returns
+`(timesteps int64 [B], importance weights float32 [B])` on `device`, and the timesteps come from ONE
+`np.random.choice(T, size=(B,), p=uniform)` call on NumPy's global generator, so `np.random.seed(s)` reproduces the
+reference's draws exactly.  `ClassifierTrainer` draws on the device instead unless a sampler is handed to it.
 """
 import numpy as np
 import torch
 
 
 class UniformSampler:
+    """Every timestep of the diffusion is equally likely; the importance weight of each draw is therefore 1."""
+
     def __init__(self, diffusion):
         self.diffusion = diffusion
-        self._weights = np.ones([diffusion.num_timesteps])
+        self.num_timesteps = int(diffusion.num_timesteps)
 
     def weights(self):
-        return self._weights
+        return np.full(self.num_timesteps, 1.0)
 
     def sample(self, batch_size, device):
-        w = self.weights()
-        p = w / np.sum(w)
-        indices_np = np.random.choice(len(p), size=(batch_size,), p=p)
-        indices = torch.from_numpy(indices_np).long().to(device)
-        weights = torch.from_numpy(1 / (len(p) * p[indices_np])).float().to(device)
-        return indices, weights
+        T = self.num_timesteps
+        prob = self.weights() / float(T)                       # == w / w.sum(): the sum of T ones is exactly T
+        drawn = np.random.choice(T, size=(batch_size,), p=prob)
+        t = torch.as_tensor(drawn, dtype=torch.long).to(device)
+        # 1 / (T * p[t]) of the general importance sampler; with p = 1/T it is exactly one
+        importance = torch.as_tensor(1.0 / (T * prob[drawn]), dtype=torch.float32).to(device)
+        return t, importance
 
 
 def create_named_schedule_sampler(name, diffusion):
-    if name == "uniform":
-        return UniformSampler(diffusion)
-    raise NotImplementedError(f"unknown schedule sampler: {name} (ClavaDDPM only uses 'uniform')")
+    if name != "uniform":
+        raise NotImplementedError(f"unknown schedule sampler: {name} (ClavaDDPM only uses 'uniform')")
+    return UniformSampler(diffusion)

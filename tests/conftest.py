@@ -32,6 +32,16 @@ def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elem_excess(a, b, rtol=1e-4, floor=1e-6):
+    """Element-wise relative check (north_star: "within 1e-4 relative error" for numeric columns and losses): the largest
+    |a - b| / (rtol * |b| + floor * max|b|) over all elements; <= 1 means every element is within `rtol` of its own
+    reference value, with an absolute floor of `floor` x the tensor's largest magnitude for elements near zero (a
+    max-norm ratio like `relerr` hides errors of small elements next to large ones)."""
+    a, b = a.double(), b.double()
+    tol = rtol * b.abs() + floor * b.abs().max().clamp_min(1e-30)
+    return float(((a - b).abs() / tol).max())
+
+
 @pytest.fixture(scope="session")
 def gold():
     return golden

@@ -96,3 +96,206 @@ def test_california_guided_chain_vs_oracle(mode):
     finally:
         split_nets.set_gemm_mode("f16x3")
     assert relerr(x, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The remaining BASELINE.json configurations at their own shapes, against the oracle.
+from conftest import elem_excess  # noqa: E402
+
+
+def _guided_setup(n_num, C, T, ps_seed, cs_seed):
+    ps = seeded_state(mlp_shapes(n_num, DL), ps_seed, scale=0.5)
+    cs = seeded_state(classifier_shapes(n_num, C, CL), cs_seed)
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(DL), "dropout": 0.0})
+    net.load_state_dict(ps)
+    clf = Classifier(d_in=n_num, d_out=C, dim_t=128, hidden_sizes=CL)
+    clf.load_state_dict(cs)
+    d = GaussianMultinomialDiffusion(np.array([0]), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    return ps, cs, d, clf.to(DEV).eval()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+@pytest.mark.parametrize("n_num", [1, 2, 5])
+def test_movie_lens_guided_chain_vs_oracle(n_num, mode):
+    """configs[1] (the headline workload): movie_lens relations have 1-5 numeric columns, 50 clusters, T = 2000, the real
+    [512,1024x4,512] denoiser and the 7-layer classifier; 256 rows x 5 guided steps on injected noise."""
+    C, T, b, steps = 50, 2000, 256, 5
+    ps, cs, d, clf = _guided_setup(n_num, C, T, 51 + n_num, 61 + n_num)
+    g = torch.Generator().manual_seed(100 + n_num)
+    ys = torch.randint(0, C, (b, 1), generator=g)
+    nz = {"z0": torch.randn(b, n_num, generator=g), "noise": torch.randn(steps, b, n_num, generator=g).double()}
+    tb = schedule.tables("cosine", T)
+    ref = chain.conditional_sample(tb, T, ps, n_num, lambda x, t: guidance.cond_grad(cs, x, t, ys, 1.0), nz, steps=steps)
+    split_nets.set_gemm_mode(mode)
+    n0 = split_nets.fallback_count
+    try:
+        x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1.0), noise=nz, n_steps=steps)
+    finally:
+        split_nets.set_gemm_mode("f16x3")
+    assert split_nets.fallback_count == n0
+    assert relerr(x, ref) < 1e-4
+    assert elem_excess(x, ref) <= 1.0            # every element within 1e-4 of its own reference value
+
+
+@pytest.mark.parametrize("n_num,C", [(8, 50), (4, 20), (20, 20)], ids=["instacart_d8_c50", "berka_d4_c20", "berka_d20_c20"])
+def test_instacart_berka_batched_rows_vs_oracle(n_num, C):
+    """configs[3] / configs[2] shapes through the sharded batching loop (`pipeline_utils.py:880-895`): 300 rows in batches of
+    128 (128 + 128 + a short last batch of 44), first 3 steps against the oracle on injected noise; then, on the in-kernel
+    generator, the table must not depend on how the rows were cut into batches or ranks (row-offset invariance)."""
+    from clavaddpm_amd import parallel
+    T, N, steps = 2000, 300, 3
+    ps, cs, d, clf = _guided_setup(n_num, C, T, 70 + n_num, 80 + C)
+    cf = make_cond_fn(clf, 1.0)
+    g = torch.Generator().manual_seed(n_num * C)
+    ys = torch.randint(0, C, (N,), generator=g)
+    nz = {"z0": torch.randn(N, n_num, generator=g), "noise": torch.randn(steps, N, n_num, generator=g).double()}
+    tb = schedule.tables("cosine", T)
+    ref = chain.conditional_sample(tb, T, ps, n_num, lambda x, t: guidance.cond_grad(cs, x, t, ys.reshape(-1, 1), 1.0), nz, steps=steps)
+    x, lab = parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=128, seed=0, rank=0, world=1, gather=False, noise=nz, n_steps=steps)
+    assert x.shape == (N, n_num) and torch.equal(lab.reshape(-1), ys)
+    assert relerr(x, ref) < 1e-4 and elem_excess(x, ref) <= 1.0
+    one = parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=512, seed=21, rank=0, world=1, gather=False, n_steps=4)[0]
+    cut = parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=128, seed=21, rank=0, world=1, gather=False, n_steps=4)[0]
+    ranks = [parallel.conditional_sample_rows(d, ys, cf, sample_batch_size=100, seed=21, rank=r, world=2, gather=False, n_steps=4)[0] for r in range(2)]
+    assert torch.equal(one, cut) and torch.equal(one, torch.cat(ranks)) and torch.isfinite(one).all()
+
+
+def _masked_oracle_grads(state, x_in, t, n_num, K, T, tb, log_cat, log_cat_t, noise, masks):
+    """Exact-normaliser oracle of one training step in float64, with the ReLU on/off pattern of every hidden block taken from
+    `masks` (the HIP path's own activations): every operation is then smooth, so the comparison is immune to the rare
+    pre-activation that sits within float32 rounding of the kink (one flipped unit of one row moves that layer's weight
+    gradient by ~1/B of its size, 2e-3 here, in ANY two float32 implementations).  Returns (loss_multi, loss_gauss,
+    {name: gradient}, [pre-activations])."""
+    import torch.nn.functional as F
+    from oracle import multinomial as mn
+    from oracle.network import n_blocks, time_mlp
+    p = {k: v.double().requires_grad_(True) for k, v in state.items()}
+    h = F.linear(x_in.double(), p["proj.weight"], p["proj.bias"]) + time_mlp(p, "time_embed.", t, 128)
+    zs = []
+    for i in range(n_blocks(p)):
+        z = F.linear(h, p[f"mlp.blocks.{i}.linear.weight"], p[f"mlp.blocks.{i}.linear.bias"])
+        zs.append(z.detach())
+        h = z * masks[i].double()
+    out = F.linear(h, p["mlp.head.weight"], p["mlp.head.bias"])
+    pt = torch.ones_like(t).float() / T
+    lm = (mn.multinomial_loss(tb, out[:, n_num:].float(), log_cat, log_cat_t, t, pt, K, T, True) / len(K)).mean()
+    lg = ((noise.double() - out[:, :n_num]) ** 2).mean(dim=1).mean()
+    (lm.double() + lg).backward()
+    return float(lm), float(lg), {k: v.grad for k, v in p.items()}, zs
+
+
+def test_scale_sweep_training_step_vs_oracle():
+    """configs[4] is a TRAINING configuration (100 numeric + 50 categorical columns, sum K = 8297): `mixed_loss` and every
+    parameter gradient of one step at batch 256 against the exact-normaliser oracle (the arithmetic the kernels implement),
+    on both training paths: the float32-input MFMA kernels (the calibration step) and split-f16 with the wide end layers
+    (D_in >= 256) and split weight gradients active.  Gradients are compared at 1e-4 given the path's own ReLU pattern
+    (see `_masked_oracle_grads`), and that pattern may differ from the oracle's only where the pre-activation is within
+    float32 rounding of zero; losses at 1e-4; the float32 restatement of the reference's own normaliser is a loose check."""
+    from clavaddpm_amd import ops, training as tr
+    from oracle import loss as oloss, multinomial as mn
+    K = _scale_sweep_K()
+    n_num, m, sumK, T, B = 100, len(K), sum(K), 1000, 256
+    D = n_num + sumK
+    state = seeded_state(mlp_shapes(D, DL), 31, scale=0.5)
+    net = MLPDiffusion(D, 0, "none", {"d_layers": list(DL), "dropout": 0.0})
+    net.load_state_dict(state)
+    net = net.to(DEV).train()
+    d = GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=T, device=torch.device(DEV)).to(DEV).train()
+    g = torch.Generator().manual_seed(17)
+    x = torch.cat([torch.randn(B, n_num, generator=g)] + [torch.randint(0, k, (B, 1), generator=g).float() for k in K], dim=1)
+    t = torch.randint(0, T, (B,), generator=g)
+    t[:5] = 0                                                  # decoder-NLL rows
+    noise, u = torch.randn(B, n_num, generator=g), torch.rand(B, sumK, generator=g)
+    tb = schedule.tables("cosine", T)
+    # the float32 oracles (exact / reference normaliser): losses
+    with torch.no_grad():
+        em, eg = [float(v) for v in oloss.mixed_loss(tb, T, state, x, n_num, K, t, noise, u, exact_norm=True)]
+        fm, _ = [float(v) for v in oloss.mixed_loss(tb, T, state, x, n_num, K, t, noise, u, exact_norm=False)]
+    # the noised input of the step, on the device and in the oracle: identical (exact category draws)
+    td, nd, ud = t.to(DEV), noise.to(DEV).contiguous(), u.to(DEV).contiguous()
+    x_in, idx0, idxt = tr.noised_input(d, x.to(DEV), td, nd, ud, 0)
+    log_cat = mn.index_to_log_onehot(x[:, n_num:].long(), K)
+    idx_t_ref = mn.sample_categorical(mn.q_pred(tb, log_cat, t, K), u, K)
+    assert torch.equal(idxt.cpu().long(), idx_t_ref)
+    log_cat_t = mn.index_to_log_onehot(idx_t_ref, K)
+    assert torch.equal(x_in[:, n_num:].cpu(), log_cat_t)
+    layout = tr.FlatLayout(net)
+
+    def check(name, lm, lg, slabs, acts):
+        flat = slabs.double().sum(0).cpu()
+        masks = [(a > 0).cpu() for a in acts]
+        rm, rg, grads, zs = _masked_oracle_grads(state, x_in.cpu(), t, n_num, K, T, tb, log_cat, log_cat_t, noise, masks)
+        assert abs(float(lg) - eg) <= 1e-4 * abs(eg) and abs(float(lm) - em) <= 1e-4 * abs(em), name
+        assert abs(float(lg) - rg) <= 1e-4 * abs(rg) and abs(float(lm) - rm) <= 1e-4 * abs(rm), name
+        # The reference normalises each categorical block by the difference of two float32 logcumsumexp values taken over
+        # the WHOLE 8297-wide row (tab_ddpm/utils.py:151-166).  On this table that cancellation moves the reference's own
+        # loss by 2.8e-3 and its parameter gradients by 2-8 % relative to the exact normaliser (CPU, oracle exact vs
+        # restated), so the restatement of that normaliser is only a loose check here.
+        assert abs(float(lm) - fm) <= 1e-2 * abs(fm), name
+        flips = 0
+        for z, mk in zip(zs, masks):
+            diff = (z > 0) != mk
+            flips += int(diff.sum())
+            assert not bool(diff.any()) or float(z[diff].abs().max()) < 1e-4 * float(z.abs().max()), name
+        assert flips <= 16, (name, flips)                      # of 256 x 5120 hidden units
+        # north_star's bar (1e-4).  Tighter is not meaningful on this table in float32: -w + W exp(lm) subtracts a true and a
+        # model posterior that are both within 1e-2 of one on most rows, so d(loss)/d(logits) carries ~1e-5 of its largest
+        # element in ANY float32 evaluation (measured against the float64 oracle: this kernel 9.9e-6, torch's own float32
+        # ops on the same GPU 2.2e-6, a NumPy float32 transcription of the kernel's formulas 5.9e-6), and the parameter
+        # gradients, sums over rows in which the signal cancels and the rounding does not, 4.6e-5.  The 10-class fixture
+        # (tests/test_gpu_training.py) holds 2e-5.
+        for n in layout.names:
+            assert relerr(layout.view(flat, n), grads[n]) < 1e-4, (name, n)
+        return flips
+
+    # ---- float32-input MFMA kernels (what the first / every 200th step of the Trainer runs)
+    out32, saved32 = tr.denoiser_forward(net, x_in, td)
+    lm, lg, d_out = tr.loss_and_grad(d, out32, nd, idx0, idxt, td)
+    slabs = torch.zeros((tr.GRAD_SPLITS, layout.total), device=DEV)
+    gs = [None] * len(saved32[4])
+    tr.denoiser_backward(net, saved32, d_out, layout, slabs, collect=gs)
+    check("f32", lm, lg, slabs, saved32[4][1:-1])
+    # ---- split-f16 step with wide end layers and split weight gradients, scales fixed by the float32 step above
+    st = tr.SplitTrainState()
+    st.calibrate(net.stack()[0], saved32[4], gs, x_in=x_in, d_out=d_out)
+    assert D >= tr.WIDE_END_LAYERS and tr.wgrad_split_ok(B)
+    out16, saved16 = tr.denoiser_forward_split(net, x_in, td, st)
+    lm16, lg16, d_out16 = tr.loss_and_grad(d, out16, nd, idx0, idxt, td)
+    slabs16 = torch.full((tr.GRAD_SPLITS, layout.total), float("nan"), device=DEV)
+    tr.denoiser_backward_split(net, saved16, d_out16, layout, slabs16, st)
+    torch.cuda.synchronize()
+    assert int(st.flag.item()) == 0 and saved16[6] is not None                  # no overflow; the wide path was taken
+    acts16 = [ops.split_unpack(hs) for hs in saved16[5][1:]]
+    check("f16x3", lm16, lg16, slabs16, acts16)
+    assert relerr(out16, out32) < 1e-5
+
+
+def test_fused_guided_sample_honours_model_kwargs_labels():
+    """`conditional_sampling` (`pipeline_utils.py:1001-1012`) calls `diffusion.sample(model_kwargs={'y': classes},
+    cond_fn=cond_fn)` and records `classes` as the rows' clusters: the fused chain must guide towards THOSE labels
+    (`cond_fn(x, t, **model_kwargs)`, `:315-328`), not towards the labels `sample` draws from `y_dist`."""
+    n_num, C, T, b, steps = 3, 20, 1000, 192, 2
+    ps, cs, d, clf = _guided_setup(n_num, C, T, 91, 92)
+    # a guidance scale at which the labels visibly steer two steps (much larger scales turn the rare LeakyReLU unit that sits
+    # within float32 rounding of its kink into a visible jump of the sample, in any two float32 implementations)
+    cf = make_cond_fn(clf, 20.0)
+    g = torch.Generator().manual_seed(5)
+    classes = torch.randint(0, C, (b,), generator=g)
+    drawn = torch.randint(0, C, (b,), generator=g)              # what `sample` would draw from y_dist: must NOT steer
+    nz = {"z0": torch.randn(b, n_num, generator=g), "noise": torch.randn(steps, b, n_num, generator=g).double(), "y": drawn}
+    fused, out = d.sample(b, torch.ones(C), model_kwargs={"y": classes.to(DEV)}, cond_fn=cf, noise=nz, n_steps=steps)
+    loop, _ = d.sample(b, torch.ones(C), model_kwargs={"y": classes.to(DEV)}, cond_fn=lambda x_, t_, y=None: cf(x_, t_, y=y),
+                       noise=nz, n_steps=steps)
+    tb = schedule.tables("cosine", T)
+    ref = chain.conditional_sample(tb, T, ps, n_num, lambda x, t: guidance.cond_grad(cs, x, t, classes.reshape(-1, 1), 20.0), nz, steps=steps)
+    assert torch.equal(out["y"].cpu(), drawn)                    # the returned out_dict is still the y_dist draw (:1037-1041, 1069)
+    assert relerr(fused, ref) < 1e-4 and relerr(loop, ref) < 1e-4
+    wrong = chain.conditional_sample(tb, T, ps, n_num, lambda x, t: guidance.cond_grad(cs, x, t, drawn.reshape(-1, 1), 20.0), nz, steps=steps)
+    assert relerr(fused, wrong) > 3e-4                           # the test can tell the two label sets apart
+    with pytest.raises(AssertionError):                          # the reference closure asserts `y is not None`
+        d.sample(b, torch.ones(C), model_kwargs={}, cond_fn=cf, noise=nz, n_steps=1)
+    with pytest.raises(NotImplementedError):
+        d.sample(b, torch.ones(C), model_kwargs={"y": classes, "remove_first_col": True}, cond_fn=cf, noise=nz, n_steps=1)
+    ys = classes.reshape(-1, 1)
+    with pytest.raises(AssertionError):
+        d.conditional_sample(ys=ys, model_kwargs=None, cond_fn=cf, noise=nz, n_steps=1)

@@ -224,3 +224,47 @@ def test_multinomial_kernel_every_group_width_and_block_size(K):
     # in-kernel noise: indices in range, and the same (seed, row) draws whatever the batch is cut into
     a, _ = d._categorical_step(0, logits.to(DEV), idx_t.to(DEV), t.to(DEV), None, False, seed=11, step_index=3)
     assert all(int(a[:, f].min()) >= 0 and int(a[:, f].max()) < K[f] for f in range(len(K)))
+
+
+def _reference_style_cond_fn(classifier, classifier_scale):
+    """The guidance closure as the reference pipeline writes it (`pipeline_utils.py:853-864`): plain torch autograd
+    through `classifier(x_in, t)` - no clavaddpm_amd helper - so it only works if `Classifier.forward` is differentiable
+    w.r.t. its input."""
+    import torch.nn.functional as F
+
+    def cond_fn(x, t, y=None, remove_first_col=False):
+        assert y is not None
+        with torch.enable_grad():
+            x_in = (x[:, 1:] if remove_first_col else x).detach().requires_grad_(True).float()
+            log_probs = F.log_softmax(classifier(x_in, t), dim=-1)
+            selected = log_probs[range(len(log_probs)), y.view(-1)]
+            return torch.autograd.grad(selected.sum(), x_in)[0] * classifier_scale
+    return cond_fn
+
+
+@pytest.mark.parametrize("tag", ["small", "real"])
+def test_g7_reference_closure_runs_unchanged_on_the_hip_classifier(tag):
+    g = golden("g7_classifier.npz")
+    hidden, C = g[f"{tag}_hidden"].tolist(), int(g[f"{tag}_C"])
+    x, t, y = g[f"{tag}_x"].to(DEV), g[f"{tag}_t"].to(DEV), g[f"{tag}_y"].to(DEV)
+    clf = _classifier(g, "small_p:" if tag == "small" else None, x.shape[1], C, hidden)
+    grad = _reference_style_cond_fn(clf, 1.5)(x, t, y=y)
+    assert grad.shape == x.shape and grad.dtype == torch.float32
+    assert relerr(grad.cpu(), g[f"{tag}_grad"]) < 1e-4
+    fused = make_cond_fn(clf, 1.5)(x, t, y=y)
+    assert relerr(grad, fused) < 1e-5
+    # float64 chain state in (as `condition_mean` hands it over, :315-328): the closure's own .float() is the only cast
+    grad64 = _reference_style_cond_fn(clf, 1.5)(x.double(), t, y=y)
+    assert torch.equal(grad64, grad)
+    with torch.no_grad():                                        # and without grad mode nothing is recorded
+        assert not clf(x.float(), t).requires_grad
+
+
+def test_g5_chain_with_the_reference_closure():
+    g = golden("g5_chain_cond.npz")
+    T, n_num, C = int(g["T"]), int(g["n_num"]), int(g["C"])
+    d = make_diffusion([0], n_num, make_mlp(n_num, [64, 64], sub(g, "p:")), T)
+    clf = _classifier(g, "c:", n_num, C, g["hidden"].tolist())
+    ys = g["ys"]
+    x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys.to(DEV)}, cond_fn=_reference_style_cond_fn(clf, 1.0), noise=sub(g, "nz:"))
+    assert relerr(x, g["sample"]) < 1e-4
