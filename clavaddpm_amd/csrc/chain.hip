@@ -3,7 +3,10 @@
 // on one stream; nothing synchronises with or copies to the host.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "clava_hip.h"
+#include "fused_narrow.h"
 #include "split.h"
 #include "step.h"
 
@@ -206,6 +209,85 @@ int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, c
     return CLAVA_OK;
 }
 
+// ---- pieces of a stack for the fused narrow-stack path (fused_narrow.hip): layers [l0, l1] of the forward as separate
+// products (in = activation of layer l0-1, outs[l] = activation of layer l), and the input-gradient products l_hi .. l_lo
+// (gin = d/d(pre-activation of layer l_hi), i.e. grads[l_hi + 1]; writes grads[l] for l = l_hi .. l_lo, all split rows)
+int split_forward_range(const clava_split_net* net, int l0, int l1, const char* in, int M, char* const* outs, int* overflow,
+                        hipStream_t st) {
+    for (int l = l0; l <= l1; ++l) {
+        SplitGemmArgs g;
+        g.A = in; g.W = (const char*)net->w[l];
+        g.M = M; g.N = net->dims[l + 1]; g.Kp = (net->dims[l] + 31) & ~31; g.K = net->dims[l];
+        g.pitchA = split_pitch(net->dims[l]); g.pitchW = g.pitchA;
+        g.bias = net->b[l]; g.bias2 = nullptr; g.act = net->act[l];
+        g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
+        g.scale_acc = ldexpf(1.f, -((l == 0 ? net->shift_in : net->shift_out[l - 1]) + net->shift_w[l]));
+        g.alpha = 1.f;
+        g.scale_out = ldexpf(1.f, net->shift_out[l]);
+        g.out_split = outs[l]; g.pitchOut = split_pitch(net->dims[l + 1]);
+        g.out_f32 = nullptr; g.ldc = 0;
+        g.overflow = overflow; g.tiles_m = g.tiles_n = 0;
+        int rc = clava_launch_gemm_f16x3(g, -1, st);
+        if (rc) return rc;
+        in = outs[l];
+    }
+    return CLAVA_OK;
+}
+
+int split_grad_range(const clava_split_net* net, int l_hi, int l_lo, int M, char* const* outs, const char* gin, char* const* grads,
+                     int* overflow, hipStream_t st) {
+    for (int l = l_hi; l >= l_lo; --l) {
+        SplitGemmArgs g;
+        g.A = gin; g.W = (const char*)net->wt[l];
+        g.M = M; g.N = net->dims[l]; g.Kp = (net->dims[l + 1] + 31) & ~31; g.K = net->dims[l + 1];
+        g.pitchA = split_pitch(net->dims[l + 1]); g.pitchW = g.pitchA;
+        g.bias = nullptr; g.bias2 = nullptr; g.act = CLAVA_ACT_NONE;
+        g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
+        if (net->act[l - 1] != CLAVA_ACT_NONE) {
+            g.mask = outs[l - 1]; g.pitchMask = split_pitch(net->dims[l]); g.mask_slope = act_slope(net->act[l - 1]);
+        }
+        g.scale_acc = ldexpf(1.f, -((l == net->n_layers - 1 ? net->shift_dlast : net->shift_grad[l + 1]) + net->shift_w[l]));
+        g.alpha = 1.f;
+        g.scale_out = ldexpf(1.f, net->shift_grad[l]);
+        g.out_split = grads[l]; g.pitchOut = split_pitch(net->dims[l]);
+        g.out_f32 = nullptr; g.ldc = 0;
+        g.overflow = overflow; g.tiles_m = g.tiles_n = 0;
+        int rc = clava_launch_gemm_f16x3(g, -1, st);
+        if (rc) return rc;
+        gin = grads[l];
+    }
+    return CLAVA_OK;
+}
+
+FusedLayer fused_layer(const clava_split_net* net, int l, const float* bias2) {
+    FusedLayer f;
+    f.bias = net->bf[l];
+    f.bias2 = bias2;
+    f.scale_acc = ldexpf(1.f, -((l == 0 ? net->shift_in : net->shift_out[l - 1]) + net->shift_w[l]));
+    f.scale_out = ldexpf(1.f, net->shift_out[l]);
+    f.act = net->act[l];
+    return f;
+}
+
+// Which parts of a step the fused narrow-stack kernels cover for these stacks (all decided by shapes and by the presence of
+// the fused operands; CLAVA_FUSED=0 in the environment of the Python side leaves the operands out).
+bool denoiser_fusable(const clava_chain* c, const clava_split_net* d) {
+    const int n = d->n_layers;
+    if (c->m != 0 || !d->fs_front || !d->fs_head || !d->bf || n < 3) return false;
+    if (!d->bf[0] || !d->bf[1] || !d->bf[n - 1]) return false;
+    return d->dims[0] <= 32 && d->dims[1] == 128 && clava_den_front_supports(d->dims[2]) && clava_den_head_supports(d->dims[n - 1]) &&
+           d->dims[n] <= 32 && d->act[0] == CLAVA_ACT_NONE;
+}
+bool classifier_fusable(const clava_chain* c, const clava_split_net* k) {
+    if (!k || c->m != 0 || !k->fs_front || !k->fs_tail || !k->fs_back || !k->bf || !k->wt || k->n_layers != 9) return false;
+    const int need[] = {0, 1, 2, 7, 8};
+    for (int l : need)
+        if (!k->bf[l]) return false;
+    const int* d = k->dims;
+    return d[0] <= 32 && d[1] == 128 && d[2] == 128 && d[3] == 256 && d[7] == 256 && d[8] == 128 && d[9] <= 64 &&
+           k->act[0] == CLAVA_ACT_NONE && k->act[8] == CLAVA_ACT_NONE;
+}
+
 inline long long align256(long long v) { return (v + 255) / 256 * 256; }
 
 struct SplitChainWs {
@@ -253,33 +335,49 @@ void carve_split(const clava_chain* c, const clava_split_net* d, const clava_spl
 // sequences drift out of phase and one sequence's MFMA work fills the other's prologue / epilogue-store / last-round
 // bubbles.  Streams and events are created once per device and reused; the caller's stream is forked at the start
 // of the call and joined at its end, so stream-ordered callers see an ordinary asynchronous call.
-enum { MAX_GROUPS = 4 };
+enum { MAX_GROUPS = 4, MAX_PRIOS = 4 };
 struct StreamPool {
     hipStream_t den[MAX_GROUPS] = {}, cls[MAX_GROUPS] = {};     // den[0] is never created: group 0 runs on the caller's stream
     hipEvent_t fork[MAX_GROUPS] = {}, join[MAX_GROUPS] = {};    // per-step fork/join between a group's two streams
-    hipEvent_t begin = nullptr, done[MAX_GROUPS] = {};          // whole-call fork / join with the caller's stream
+    hipEvent_t begin = nullptr, done[MAX_GROUPS] = {}, done_cls[MAX_GROUPS] = {};   // whole-call fork / join with the caller's stream
+    int priority = 0;
     bool ok = false, tried = false;
 };
-StreamPool g_pool[64];
+// One pool per (device, stream priority of the caller).  The side streams are created with the CALLER'S priority: every
+// step makes the two streams of a group wait for each other (fork: cls waits for den, join: den waits for cls), and with
+// unequal priorities the waiting side can keep the hardware queue slot from the side it waits for.  That is the most
+// probable cause of the stall recorded in round 1 (guidance stream at the highest priority, GPU_MAX_HW_QUEUES = 4, ~50 000
+// launches and ~4000 cross-stream waits enqueued without a host synchronisation: the high-priority queue's barrier
+// packets were always runnable-to-poll while the normal-priority queue that had to signal them was time-sliced out -
+// priority inversion, progress collapses but the GPU stays responsive).  Equal priorities cannot invert.
+// `g_pool_mutex[dev]` serialises whole chain calls of one device: the pool's streams and events are shared by every host
+// thread, and two interleaved enqueues would wait on each other's re-recorded events.
+StreamPool g_pool[64][MAX_PRIOS];
+std::mutex g_pool_mutex[64];
 
-StreamPool* stream_pool() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    StreamPool& p = g_pool[dev];
-    if (!p.tried) {
-        p.tried = true;
-        bool ok = hipEventCreateWithFlags(&p.begin, hipEventDisableTiming) == hipSuccess;
+StreamPool* stream_pool(int dev, hipStream_t caller) {
+    int prio = 0;
+    if (hipStreamGetPriority(caller, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    StreamPool* p = nullptr;
+    for (int i = 0; i < MAX_PRIOS && !p; ++i)
+        if (g_pool[dev][i].tried ? g_pool[dev][i].priority == prio : true) p = &g_pool[dev][i];
+    if (!p) return nullptr;                   // more distinct caller priorities than slots: run on one stream
+    if (!p->tried) {
+        p->tried = true;
+        p->priority = prio;
+        bool ok = hipEventCreateWithFlags(&p->begin, hipEventDisableTiming) == hipSuccess;
         for (int g = 0; g < MAX_GROUPS && ok; ++g) {
-            ok = (g == 0 || hipStreamCreateWithFlags(&p.den[g], hipStreamNonBlocking) == hipSuccess) &&
-                 hipStreamCreateWithFlags(&p.cls[g], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&p.fork[g], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&p.join[g], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&p.done[g], hipEventDisableTiming) == hipSuccess;
+            ok = (g == 0 || hipStreamCreateWithPriority(&p->den[g], hipStreamNonBlocking, prio) == hipSuccess) &&
+                 hipStreamCreateWithPriority(&p->cls[g], hipStreamNonBlocking, prio) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->fork[g], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->join[g], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->done[g], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->done_cls[g], hipEventDisableTiming) == hipSuccess;
         }
         if (!ok) (void)hipGetLastError();
-        p.ok = ok;
+        p->ok = ok;
     }
-    return p.ok ? &p : nullptr;
+    return p->ok ? p : nullptr;
 }
 
 int env_int(const char* name, int dflt) {
@@ -518,35 +616,23 @@ long long clava_chain_workspace_bytes_f16x3(const clava_chain* c, const clava_sp
     return w.total;
 }
 
-int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denoiser, const clava_split_net* classifier, int B,
-                             double* x, int* idx, void* ws, long long ws_bytes, int* overflow, void* stream) {
-    int rc = check_split_chain(c, denoiser, classifier, B);
-    if (rc) return rc;
-    CLAVA_CHECK_ARG(x || c->n_num == 0, "sample_chain_f16x3: x is null");
-    CLAVA_CHECK_ARG(idx || c->m == 0, "sample_chain_f16x3: idx is null");
-    CLAVA_CHECK_ARG(overflow, "sample_chain_f16x3: the overflow flag is required");
-    SplitChainWs w;
-    carve_split(c, denoiser, classifier, B, (char*)ws, w);
-    CLAVA_CHECK_ARG(ws && ws_bytes >= w.total && ((uintptr_t)ws & 255) == 0,
-                    "sample_chain_f16x3: workspace of %lld bytes (256-byte aligned) needed, %lld given", w.total, ws_bytes);
-    const hipStream_t caller = (hipStream_t)stream;
-    const clava_split_net* d = denoiser;
-    const clava_split_net* k = classifier;
+}  // extern "C"
+
+// The enqueue of one split-f16 chain.  `groups` / `ng` tell the caller which streams were forked off its own, so that it can
+// join them back whatever this function returns.
+struct ChainGroup { int r0, rows; hipStream_t den, cls; };
+
+static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, const clava_split_net* k, int B, double* x, int* idx,
+                               const SplitChainWs& w, int* overflow, hipStream_t caller, StreamPool* pool, int n_groups, bool side,
+                               ChainGroup* groups, int& ng) {
+    int rc = CLAVA_OK;
     const int D = d->dims[0], nd = d->n_layers;
     const int emb_w = d->dims[1];
-
-    // ---- row groups and their streams (CLAVA_CHAIN_GROUPS / CLAVA_CHAIN_STREAMS override the defaults; 1 / 1 = fully serial)
-    StreamPool* pool = stream_pool();
-    int n_groups = env_int("CLAVA_CHAIN_GROUPS", 1);
-    n_groups = n_groups < 1 ? 1 : (n_groups > MAX_GROUPS ? MAX_GROUPS : n_groups);
-    const bool side = pool && k && env_int("CLAVA_CHAIN_STREAMS", 2) >= 2;
-    if (!pool) n_groups = 1;
     const int rows_per = ((B + n_groups - 1) / n_groups + 63) / 64 * 64;     // whole 64-row blocks per group
+    const bool den_fused = c->n_num > 0 && denoiser_fusable(c, d);
+    const bool cls_fused = classifier_fusable(c, k);
     if (n_groups > 1) CLAVA_CHECK_HIP(hipEventRecord(pool->begin, caller), "sample_chain_f16x3: fork");
-
-    struct Group { int r0, rows; hipStream_t den, cls; };
-    Group groups[MAX_GROUPS];
-    int ng = 0;
+    typedef ChainGroup Group;
     for (int g = 0; g < n_groups; ++g) {
         const int r0 = g * rows_per;
         if (r0 >= B) break;
@@ -589,8 +675,24 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
             char* outs[64];
             for (int l = 0; l < nd - 1; ++l) outs[l] = rowp(w.den[l & 1], split_pitch(hw), r0);
             outs[nd - 1] = nullptr;
-            rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, D, overflow, G.den);
-            if (rc) return rc;
+            if (den_fused) {
+                // proj + first hidden block in one kernel; the head runs fused with the Gaussian step below
+                FusedFrontArgs fa;
+                fa.B = R; fa.x = x_split; fa.pitch_x = split_pitch(D);
+                fa.stream = (const char*)d->fs_front;
+                fa.l[0] = fused_layer(d, 0, c->denoiser_emb + (size_t)t * emb_w);
+                fa.l[1] = fused_layer(d, 1, nullptr);
+                fa.nt_out = d->dims[2] / 32;
+                fa.out = outs[1]; fa.pitch_out = split_pitch(d->dims[2]);
+                fa.overflow = overflow;
+                rc = clava_launch_den_front(fa, D, G.den);
+                if (rc) return rc;
+                rc = split_forward_range(d, 2, nd - 2, outs[1], R, outs, overflow, G.den);
+                if (rc) return rc;
+            } else {
+                rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, D, overflow, G.den);
+                if (rc) return rc;
+            }
             // ---- guidance: grad_x log p(y | x_t), on the group's second stream
             const float* grad = nullptr;
             if (k) {
@@ -602,20 +704,69 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
                 float* logits = w.logits + (size_t)r0 * C;
                 char* dlogits = rowp(w.dlogits, split_pitch(C), r0);
                 float* gx = w.gx + (size_t)r0 * c->n_num;
-                rc = split_net_forward(k, x_split, R, c->classifier_emb + (size_t)t * k->dims[1], cls_out, logits, C, overflow, st);
-                if (rc) return rc;
-                {
-                    ProfScope prof(PROF_SELECT_GRAD, 0.0, 8.0 * R * C, st);
-                    hipLaunchKernelGGL(logsoftmax_select_grad_split_kernel, dim3((R + 3) / 4), dim3(256), 0, st, logits, C, c->y + r0,
-                                       dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), R, C);
-                    CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
-                }
                 const int gw = max_width_dims(k->dims, 1, nk - 1);
                 char* grads[64];
                 for (int l = 1; l < nk; ++l) grads[l] = rowp(w.cls_grad[l & 1], split_pitch(gw), r0);
                 grads[0] = nullptr;
-                rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st);
-                if (rc) return rc;
+                if (cls_fused) {
+                    // front (3 layers) -> 4 wide products -> tail (2 layers, log-softmax gradient, 2 input-gradient products)
+                    // -> 4 wide input-gradient products -> back (3 input-gradient products): 11 launches instead of 19
+                    const float* emb = c->classifier_emb + (size_t)t * k->dims[1];
+                    FusedFrontArgs fa;
+                    fa.B = R; fa.x = x_split; fa.pitch_x = split_pitch(D);
+                    fa.stream = (const char*)k->fs_front;
+                    fa.l[0] = fused_layer(k, 0, emb); fa.l[1] = fused_layer(k, 1, nullptr); fa.l[2] = fused_layer(k, 2, nullptr);
+                    fa.nt_out = 8;
+                    fa.out = cls_out[2]; fa.pitch_out = split_pitch(256);
+                    fa.overflow = overflow;
+                    rc = clava_launch_cls_front(fa, c->n_num, st);
+                    if (rc) return rc;
+                    rc = split_forward_range(k, 3, 6, cls_out[2], R, cls_out, overflow, st);
+                    if (rc) return rc;
+                    FusedTailArgs ta;
+                    ta.B = R; ta.C = C;
+                    ta.a6 = cls_out[6]; ta.pitch_a6 = split_pitch(256);
+                    ta.y = c->y + r0;
+                    ta.l7 = fused_layer(k, 7, nullptr); ta.l8 = fused_layer(k, 8, nullptr);
+                    ta.stream = (const char*)k->fs_tail;
+                    ta.scale_dlast = ldexpf(1.f, k->shift_dlast);
+                    ta.scale_acc_g8 = ldexpf(1.f, -(k->shift_dlast + k->shift_w[8]));
+                    ta.scale_out_g8 = ldexpf(1.f, k->shift_grad[8]); ta.slope7 = act_slope(k->act[7]);
+                    ta.scale_acc_g7 = ldexpf(1.f, -(k->shift_grad[8] + k->shift_w[7]));
+                    ta.scale_out_g7 = ldexpf(1.f, k->shift_grad[7]); ta.slope6 = act_slope(k->act[6]);
+                    ta.out = grads[7]; ta.pitch_out = split_pitch(256);
+                    ta.overflow = overflow;
+                    rc = clava_launch_cls_tail(ta, st);
+                    if (rc) return rc;
+                    rc = split_grad_range(k, 6, 3, R, cls_out, grads[7], grads, overflow, st);
+                    if (rc) return rc;
+                    FusedBackArgs ba;
+                    ba.B = R; ba.n_num = c->n_num;
+                    ba.x = x_split; ba.pitch_x = split_pitch(D);
+                    ba.g3 = grads[3]; ba.pitch_g3 = split_pitch(256);
+                    ba.l[0] = fused_layer(k, 0, emb); ba.l[1] = fused_layer(k, 1, nullptr);
+                    ba.stream = (const char*)k->fs_back;
+                    ba.scale_acc_g2 = ldexpf(1.f, -(k->shift_grad[3] + k->shift_w[2]));
+                    ba.scale_out_g2 = ldexpf(1.f, k->shift_grad[2]); ba.slope1 = act_slope(k->act[1]);
+                    ba.scale_acc_g1 = ldexpf(1.f, -(k->shift_grad[2] + k->shift_w[1]));
+                    ba.scale_out_g1 = ldexpf(1.f, k->shift_grad[1]);
+                    ba.scale_acc_g0 = c->guidance_scale * ldexpf(1.f, -(k->shift_grad[1] + k->shift_w[0]));
+                    ba.gx = gx; ba.ld_gx = c->n_num;
+                    ba.overflow = overflow;
+                    rc = clava_launch_cls_back(ba, st);
+                    if (rc) return rc;
+                } else {
+                    rc = split_net_forward(k, x_split, R, c->classifier_emb + (size_t)t * k->dims[1], cls_out, logits, C, overflow, st);
+                    if (rc) return rc;
+                    {
+                        ProfScope prof(PROF_SELECT_GRAD, 0.0, 8.0 * R * C, st);
+                        hipLaunchKernelGGL(logsoftmax_select_grad_split_kernel, dim3((R + 3) / 4), dim3(256), 0, st, logits, C, c->y + r0,
+                                           dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), R, C);
+                        CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
+                    }
+                    rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st);
+                    if (rc) return rc;
+                }
                 grad = gx;
                 if (G.cls != G.den) {
                     CLAVA_CHECK_HIP(hipEventRecord(pool->join[gi], G.cls), "sample_chain_f16x3: step join");
@@ -637,7 +788,18 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
                 g.t_rows = nullptr; g.t = t;
                 g.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
                 g.seed = c->seed; g.row_offset = c->row_offset + (unsigned long long)r0; g.step_index = step_index;
-                rc = clava_launch_gauss_step(g, G.den);
+                if (den_fused) {               // the head's eps goes from the accumulators straight into the step
+                    FusedHeadArgs ha;
+                    ha.stream = (const char*)d->fs_head;
+                    ha.h = outs[nd - 2]; ha.pitch_h = split_pitch(d->dims[nd - 1]);
+                    ha.ks = d->dims[nd - 1] / 16;
+                    ha.l = fused_layer(d, nd - 1, nullptr);
+                    ha.g = g;
+                    ha.g.eps = nullptr; ha.g.ld_eps = 0;
+                    rc = clava_launch_den_head_gauss(ha, G.den);
+                } else {
+                    rc = clava_launch_gauss_step(g, G.den);
+                }
                 if (rc) return rc;
             }
             // ---- fused categorical step (writes the log-one-hot of the new indices into the next denoiser input)
@@ -659,12 +821,54 @@ int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denois
             }
         }
     }
-    // ---- join every group's stream back into the caller's
-    for (int gi = 1; gi < ng; ++gi) {
-        CLAVA_CHECK_HIP(hipEventRecord(pool->done[gi], groups[gi].den), "sample_chain_f16x3: join");
-        CLAVA_CHECK_HIP(hipStreamWaitEvent(caller, pool->done[gi], 0), "sample_chain_f16x3: join");
-    }
     return CLAVA_OK;
+}
+
+extern "C" {
+
+int clava_sample_chain_f16x3(const clava_chain* c, const clava_split_net* denoiser, const clava_split_net* classifier, int B,
+                             double* x, int* idx, void* ws, long long ws_bytes, int* overflow, void* stream) {
+    int rc = check_split_chain(c, denoiser, classifier, B);
+    if (rc) return rc;
+    CLAVA_CHECK_ARG(x || c->n_num == 0, "sample_chain_f16x3: x is null");
+    CLAVA_CHECK_ARG(idx || c->m == 0, "sample_chain_f16x3: idx is null");
+    CLAVA_CHECK_ARG(overflow, "sample_chain_f16x3: the overflow flag is required");
+    SplitChainWs w;
+    carve_split(c, denoiser, classifier, B, (char*)ws, w);
+    CLAVA_CHECK_ARG(ws && ws_bytes >= w.total && ((uintptr_t)ws & 255) == 0,
+                    "sample_chain_f16x3: workspace of %lld bytes (256-byte aligned) needed, %lld given", w.total, ws_bytes);
+    const hipStream_t caller = (hipStream_t)stream;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+    // ---- row groups and their streams (CLAVA_CHAIN_GROUPS / CLAVA_CHAIN_STREAMS override the defaults; 1 / 1 = fully serial).
+    // The pool is shared by all host threads of the device: one chain is enqueued at a time.
+    std::lock_guard<std::mutex> lock(g_pool_mutex[dev]);
+    StreamPool* pool = stream_pool(dev, caller);
+    int n_groups = env_int("CLAVA_CHAIN_GROUPS", 1);
+    n_groups = n_groups < 1 ? 1 : (n_groups > MAX_GROUPS ? MAX_GROUPS : n_groups);
+    const bool side = pool && classifier && env_int("CLAVA_CHAIN_STREAMS", 2) >= 2;
+    if (!pool) n_groups = 1;
+    ChainGroup groups[MAX_GROUPS];
+    int ng = 0;
+    rc = enqueue_split_chain(c, denoiser, classifier, B, x, idx, w, overflow, caller, pool, n_groups, side, groups, ng);
+    // ---- join every forked stream back into the caller's, on success AND on failure: an error between a step's fork and its
+    // join must not leave a side stream running behind the caller's back (the caller frees the workspace next)
+    int rc_join = CLAVA_OK;
+    for (int gi = 0; gi < ng; ++gi) {
+        const ChainGroup& G = groups[gi];
+        if (G.den != caller) {
+            if (hipEventRecord(pool->done[gi], G.den) != hipSuccess || hipStreamWaitEvent(caller, pool->done[gi], 0) != hipSuccess) rc_join = CLAVA_ERR_LAUNCH;
+        }
+        if (G.cls != G.den && (rc != CLAVA_OK || G.den != caller)) {
+            if (hipEventRecord(pool->done_cls[gi], G.cls) != hipSuccess || hipStreamWaitEvent(caller, pool->done_cls[gi], 0) != hipSuccess) rc_join = CLAVA_ERR_LAUNCH;
+        }
+    }
+    if (rc == CLAVA_OK && rc_join != CLAVA_OK) {
+        (void)hipGetLastError();
+        clava_set_error("sample_chain_f16x3: joining the side streams failed");
+        return rc_join;
+    }
+    return rc;
 }
 
 }  // extern "C"

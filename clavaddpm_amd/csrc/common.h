@@ -35,7 +35,8 @@ enum ProfFamily {
     PROF_GEMM_TN_128, PROF_GEMM_TN_64,
     PROF_GAUSS_STEP, PROF_MULTI_STEP, PROF_SELECT_GRAD, PROF_MISC, PROF_LOSS, PROF_ADAMW, PROF_GMM, PROF_BN,
     PROF_GEMM_F16X3,                                   // first of PROF_GEMM_F16X3_CFGS families, one per tile configuration
-    PROF_N_FAMILIES = PROF_GEMM_F16X3 + 10
+    PROF_FUSED_NARROW = PROF_GEMM_F16X3 + 10,          // fused_narrow.hip
+    PROF_N_FAMILIES
 };
 enum { PROF_GEMM_F16X3_CFGS = 10 };
 extern bool g_clava_prof_on;

@@ -23,55 +23,12 @@ namespace {
 
 constexpr float LOG_TINY = -69.07755279541016f;   // log(float32(1e-30)): value of log(clamp(onehot, 1e-30)) off the hot class
 
-// one element of a split row (split.h): both planes, 2-byte stores
-__device__ __forceinline__ void store_split(const SplitOut& o, int row, int col, float v) {
-    const float sc = v * o.scale;
-    if (!(fabsf(sc) <= 65504.f) && o.overflow) *o.overflow = 1;
-    const _Float16 hi = (_Float16)sc;
-    const _Float16 lo = (_Float16)(sc - (float)hi);
-    _Float16* p = reinterpret_cast<_Float16*>(o.base + (long long)row * o.pitch + (long long)(col >> 5) * 128) + (col & 31);
-    p[0] = hi;
-    p[32] = lo;
-}
-
 // ------------------------------------------------------------------------------------------------ Gaussian
 __global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
     const long long n = (long long)a.B * a.n_num;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int row = (int)(i / a.n_num), col = (int)(i - (long long)row * a.n_num);
-        const int t = a.t_rows ? (int)a.t_rows[row] : a.t;
-        const float sr = a.s.sqrt_recip_alphas_cumprod[t], srm1 = a.s.sqrt_recipm1_alphas_cumprod[t];
-        const float c1 = a.s.posterior_mean_coef1[t], c2 = a.s.posterior_mean_coef2[t];
-        const float e = a.eps[(size_t)row * a.ld_eps + col];
-        const double xd = a.x[i];
-        double pred, mean;
-        if (a.x_is_f32) {          // first step of a chain: x is the float32 draw, the reference computes in float32 (:1029)
-            const float xf = (float)xd;
-            const float pf = sr * xf - srm1 * e;
-            pred = (double)pf;
-            mean = (double)(c1 * pf + c2 * xf);
-        } else {                   // afterwards x is float64; float32 tables promote, eps * table stays a float32 product (:305-306)
-            pred = (double)sr * xd - (double)(srm1 * e);
-            mean = (double)c1 * pred + (double)c2 * xd;
-        }
-        if (a.grad) {              // condition_mean: mean.float() + variance * gradient.float()  (:325-327)
-            const float g = a.grad[(size_t)row * a.ld_grad + col];
-            mean = (double)(float)mean + a.s.model_variance[t] * (double)g;
-        }
-        double z;
-        if (a.noise) {
-            z = a.noise[i];
-        } else {
-            const unsigned long long elem = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.n_num + col;
-            const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem, a.step_index, clava_rng::STREAM_GAUSS);
-            z = (double)clava_rng::to_normal(r.x, r.y);
-        }
-        const double keep = (t != 0) ? 1.0 : 0.0;              // nonzero_mask (:373-375)
-        const double out = mean + (keep * a.s.model_sigma[t]) * z;
-        a.x[i] = out;
-        if (a.pred_xstart) a.pred_xstart[i] = pred;
-        if (a.x_in) a.x_in[(size_t)row * a.ld_xin + col] = (float)out;
-        if (a.xs.base) store_split(a.xs, row, a.xs.col0 + col, (float)out);
+        gauss_step_element(a, row, col, a.eps[(size_t)row * a.ld_eps + col]);      // step.h
     }
 }
 

@@ -62,7 +62,12 @@ class CSplitNet(ctypes.Structure):
                 ("shift_in", ctypes.c_int),
                 ("shift_out", _native.c_int_p),
                 ("shift_grad", _native.c_int_p),
-                ("shift_dlast", ctypes.c_int)]
+                ("shift_dlast", ctypes.c_int),
+                ("fs_front", ctypes.c_void_p),
+                ("fs_tail", ctypes.c_void_p),
+                ("fs_back", ctypes.c_void_p),
+                ("fs_head", ctypes.c_void_p),
+                ("bf", ctypes.POINTER(ctypes.c_void_p))]
 
 
 def shift_for(maxabs, target=TARGET_LOG2):
@@ -83,6 +88,70 @@ def fold_batchnorm(ws, bs, sc, sh):
         fw.append(w)
         fb.append(b)
     return fw, fb
+
+
+_FUSED_IDX = {}
+FUSED_CHUNK = 32768       # bytes per LDS ring chunk of the fused kernels (csrc/fused_narrow.hip: RING_CHUNK)
+
+
+def pack_fused(w, shift, n_pad=None, k_pad=None, group=4):
+    """float32 [N, K] -> the fragments of one layer for the fused narrow-stack kernels (csrc/fused_narrow.hip), a uint8 device
+    tensor: v_mfma_f32_32x32x16_f16 fragments [group of <= `group` row tiles][k-step][row tile][plane hi/lo][lane 64][8
+    halves] of the planes hi = f16(w 2^shift), lo = f16(w 2^shift - hi); lane (r = lane & 31, h = lane >> 5) holds row
+    32 t + r, and its element j of step s is column 16 s + 8 (j >> 2) + 4 h + (j & 3): the order in which an accumulator
+    tile of the previous layer is laid out, so that layers chain in registers.  Rows / columns are zero padded to n_pad /
+    k_pad (default: multiples of 32 / 16)."""
+    N, K = w.shape
+    Np = n_pad if n_pad is not None else (N + 31) // 32 * 32
+    Kp = k_pad if k_pad is not None else (K + 15) // 16 * 16
+    nt, ks = Np // 32, Kp // 16
+    if Np % 32 or Kp % 16 or Np < N or Kp < K or (nt > group and nt % group):
+        raise _lib.ClavaHipError(f"pack_fused: padded shape [{Np}, {Kp}] does not hold [{N}, {K}] in groups of {group} tiles")
+    dev = w.device
+    wp = torch.zeros((Np, Kp), device=dev, dtype=torch.float32)
+    wp[:N, :K] = w.detach().float() * (2.0 ** shift)
+    if not bool((wp.abs() <= 65504.0).all()):
+        raise _lib.ClavaHipError("pack_fused: a scaled weight leaves the float16 range")
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+    g = min(group, nt)
+    key = (Np, Kp, g, str(dev))
+    idx = _FUSED_IDX.get(key)
+    if idx is None:
+        lane = torch.arange(64, device=dev)
+        r, h = lane & 31, lane >> 5
+        j = torch.arange(8, device=dev)
+        koff = 8 * (j >> 2) + (j & 3)
+        grp = torch.arange(nt // g, device=dev)
+        tig = torch.arange(g, device=dev)
+        s_ = torch.arange(ks, device=dev)
+        shape = (nt // g, ks, g, 64, 8)
+        rows = (32 * (g * grp[:, None, None, None, None] + tig[None, None, :, None, None]) + r[None, None, None, :, None]).expand(shape)
+        cols = (16 * s_[None, :, None, None, None] + 4 * h[None, None, None, :, None] + koff[None, None, None, None, :]).expand(shape)
+        idx = (rows * Kp + cols).reshape(-1)
+        if len(_FUSED_IDX) >= 32:
+            _FUSED_IDX.clear()
+        _FUSED_IDX[key] = idx
+    shape = (nt // g, ks, g, 1, 64, 8)
+    out = torch.cat([hi.reshape(-1)[idx].reshape(shape), lo.reshape(-1)[idx].reshape(shape)], dim=3).contiguous()
+    return out.view(torch.uint8).reshape(-1)
+
+
+def fused_stream(parts):
+    """One weight stream of a fused kernel: the layers' fragments in consumption order, zero padded to whole ring chunks."""
+    buf = torch.cat(parts)
+    pad = (-buf.numel()) % FUSED_CHUNK
+    if pad:
+        buf = torch.cat([buf, torch.zeros(pad, device=buf.device, dtype=torch.uint8)])
+    return buf.contiguous()
+
+
+def pad_bias(b, n_pad=None):
+    n = b.numel()
+    Np = n_pad if n_pad is not None else (n + 31) // 32 * 32
+    out = torch.zeros(Np, device=b.device, dtype=torch.float32)
+    out[:n] = b.detach().float()
+    return out
 
 
 def calibration_input(n_num, offsets, device):
@@ -160,6 +229,32 @@ class SplitNet:
         c.shift_in = shift_in
         c.shift_out = ctypes.cast(self._so, _native.c_int_p)
         c.shift_dlast = self.shift_dlast
+        # ---- operands of the fused narrow-stack kernels, for the parts of the configs' architectures that they cover
+        # (a <= 32-wide input, dim_t = 128; classifier: 128, 256, ..., 256, 128, <= 64 classes; denoiser: first / last hidden
+        # width 256, 512 or 1024).  Other shapes simply get no stream: the chain runs every layer as its own product then.
+        self.bf = [None] * n
+        self.fs_front = self.fs_tail = self.fs_back = self.fs_head = None
+        d = self.dims
+        pk = lambda l, **kw: pack_fused(fw[l], self.shift_w[l], **kw)
+        pkt = lambda l, **kw: pack_fused(fw[l].t().contiguous(), self.shift_w[l], **kw)
+        narrow_in = d[0] <= 32 and d[1] == 128 and os.environ.get("CLAVA_FUSED", "0") != "0"
+        if narrow_in and not need_grad and n >= 3 and d[2] in (256, 512, 1024) and d[n - 1] in (256, 512, 1024) and d[n] <= 32:
+            self.fs_front = fused_stream([pk(0), pk(1)])                         # proj, first hidden block
+            self.fs_head = fused_stream([pk(n - 1)])
+            for l in (0, 1, n - 1):
+                self.bf[l] = pad_bias(fb[l])
+        if narrow_in and need_grad and n == 9 and d[2] == 128 and d[3] == 256 and d[7] == 256 and d[8] == 128 and d[9] <= 64:
+            self.fs_front = fused_stream([pk(0), pk(1), pk(2)])
+            self.fs_tail = fused_stream([pk(7), pk(8, n_pad=64), pkt(8, k_pad=64), pkt(7)])
+            self.fs_back = fused_stream([pk(0), pk(1), pkt(2), pkt(1), pkt(0)])
+            for l in (0, 1, 2, 7):
+                self.bf[l] = pad_bias(fb[l])
+            self.bf[8] = pad_bias(fb[8], 64)
+        self._bf = _native.void_array(self.bf)
+        c.bf = ctypes.cast(self._bf, ctypes.POINTER(ctypes.c_void_p))
+        for name in ("fs_front", "fs_tail", "fs_back", "fs_head"):
+            t = getattr(self, name)
+            setattr(c, name, t.data_ptr() if t is not None else None)
         self.c = c
 
 
@@ -215,7 +310,8 @@ def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_g
     is rebuilt if it differs.  Entries keep their tensors alive, so a cached device address cannot be handed to another
     tensor by the allocator while the entry exists."""
     watch = [t.detach() for t in (watch if watch is not None else list(ws) + list(bs)) if t is not None]
-    key = tuple((t.data_ptr(), tuple(t.shape)) for t in watch) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1])
+    key = tuple((t.data_ptr(), tuple(t.shape)) for t in watch) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1],
+                                                                   os.environ.get("CLAVA_FUSED", "0"))
     hit = _cache.get(key)
     vers = _versions(watch)
     if hit is not None:

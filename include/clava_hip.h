@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 100
+#define CLAVA_HIP_VERSION 101
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
@@ -260,6 +260,20 @@ typedef struct clava_split_net {
     const int* shift_out;
     const int* shift_grad;
     int shift_dlast;
+    /* Optional operands of the fused narrow-stack kernels (csrc/fused_narrow.hip; NULL: the chain runs those layers as
+     * separate products).  Each fs_* is ONE device buffer: the weights of all layers of a fused kernel as ready-made
+     * v_mfma_f32_32x32x16_f16 fragments in the order the kernel consumes them - per layer and group of <= 4 row tiles
+     * [16-deep k-step][row tile of 32][hi, lo][lane][8 halves], element j of lane half h of step s holding column
+     * 16 s + 8 (j >> 2) + 4 h + (j & 3), zero padded to whole 32 KB chunks.  Denoiser: fs_front = proj, first hidden block;
+     * fs_head = head.  Classifier: fs_front = proj, blocks 1-2; fs_tail = block 7, logits layer, their transposes;
+     * fs_back = proj, block 1 (recomputed mask), transposes of block 2, block 1, proj.  bf[l] = b[l] zero padded to a
+     * multiple of 32 floats (64 for the logits layer), host array of n_layers device pointers.
+     * clavaddpm_amd/split_nets.py::fused_streams builds them. */
+    const void* fs_front;
+    const void* fs_tail;
+    const void* fs_back;
+    const void* fs_head;
+    const float* const* bf;
 } clava_split_net;
 
 /* Same chain as clava_sample_chain_f32 (same step kernels, same noise keys) with every nn.Linear product on

@@ -299,3 +299,35 @@ def test_fused_guided_sample_honours_model_kwargs_labels():
     ys = classes.reshape(-1, 1)
     with pytest.raises(AssertionError):
         d.conditional_sample(ys=ys, model_kwargs=None, cond_fn=cf, noise=nz, n_steps=1)
+
+
+@pytest.mark.parametrize("n_num,C", [(2, 50), (15, 25), (20, 20), (32, 64), (17, 3)])
+def test_fused_narrow_stack_kernels_match_the_per_layer_products(n_num, C, monkeypatch):
+    """The fused narrow-stack kernels (csrc/fused_narrow.hip: denoiser front / head + Gaussian step, classifier front / tail /
+    back) against the same chain run layer by layer (CLAVA_FUSED=0), on the configs' architectures: both are split-f16
+    evaluations of the same float32 products (22-bit operands, float32 accumulation in another order), so they agree to
+    float32 rounding; and against the oracle.  A batch that is not a multiple of the 32-row wavefront tile."""
+    T, b, steps = 1000, 1000 + 13, 3
+    ps, cs, d, clf = _guided_setup(n_num, C, T, 300 + n_num, 400 + C)
+    cf = make_cond_fn(clf, 3.0)
+    g = torch.Generator().manual_seed(n_num + C)
+    ys = torch.randint(0, C, (b, 1), generator=g)
+    nz = {"z0": torch.randn(b, n_num, generator=g), "noise": torch.randn(steps, b, n_num, generator=g).double()}
+    split_nets.set_gemm_mode("f16x3")
+    n0 = split_nets.fallback_count
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CLAVA_FUSED", fused)
+        out[fused], _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, noise=nz, n_steps=steps)
+    assert split_nets.fallback_count == n0
+    assert relerr(out["1"], out["0"]) < 2e-6
+    tb = schedule.tables("cosine", T)
+    sub_rows = slice(0, 200)
+    nzs = {"z0": nz["z0"][sub_rows], "noise": nz["noise"][:, sub_rows]}
+    ref = chain.conditional_sample(tb, T, ps, n_num, lambda x, t: guidance.cond_grad(cs, x, t, ys[sub_rows], 3.0), nzs, steps=steps)
+    assert relerr(out["1"][sub_rows], ref) < 1e-4 and elem_excess(out["1"][sub_rows], ref) <= 1.0
+    # the unguided Gaussian chain uses the fused denoiser ends alone
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CLAVA_FUSED", fused)
+        out[fused], _ = d.sample(b, torch.ones(1), noise=dict(nz, y=torch.zeros(b, dtype=torch.long)), n_steps=steps)
+    assert relerr(out["1"], out["0"]) < 2e-6

@@ -3,7 +3,8 @@ import ctypes
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant  # noqa: F401,E402
 import torch
 
 from clavaddpm_amd import _lib, ops
