@@ -13,11 +13,16 @@ trained values.  One "step" = one full T-step chain over one 20000-row batch on 
 GPU, no collective on the data path: weak scaling).
 
 The JSON line also carries
-  roofline     - the dominant kernel (fp32 MFMA GEMM, 128x128 tile, NT layout): algorithmic FLOPs per launch over
-                 its mean launch duration, both from HIP events recorded on the launch stream inside the timed
-                 region (clava_prof_*), against the 157.3 TFLOP/s dense fp32 matrix peak of MI355X;
+  roofline     - the dominant kernel, gemm_f16x3_kernel<256,320,2,2> (split-f16: three v_mfma_f32_16x16x32_f16 per
+                 float32 product; the 1024-wide layers of the denoiser, the classifier and its input gradient):
+                 algorithmic FLOPs (2*M*N*K of the float32 product) per launch over its mean launch duration, both from
+                 HIP events recorded on the launch stream (clava_prof_*) during a serial replay of one chain, against
+                 the 2516.8 TFLOP/s dense f16 matrix peak of MI355X.  `frac` is that algorithmic ratio;
+                 `frac_of_split_ceiling` divides by peak/3 (the most a 3-MFMA-per-product kernel can reach) and
+                 `mfma_issue_frac` is the share of matrix-core issue slots the kernel fills;
   cpu_baseline - the CPU oracle (a torch-CPU restatement of the reference path, pinned to the reference's golden
-                 vectors) timed on this box's host cores on a bounded sample of the same workload.
+                 vectors) timed on this box's host cores on a bounded sample of the same workload, once on the
+                 process's CPU share and once on one thread; `train.cpu_baseline` does the same for the training step.
 """
 import argparse
 import ctypes
@@ -76,6 +81,17 @@ def run_chain(diff, cond_fn, ys, seed, row_offset):
     return x, keep
 
 
+def cpu_share():
+    """Threads this process may use: its scheduler affinity, capped by OMP_NUM_THREADS when the box sets one (the GPU box
+    exports 16 = one GPU's share of a machine whose os.cpu_count() is many times that)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(n, omp) if omp > 0 else n)
+
+
 def cpu_baseline(n_num, n_clusters, T, batch, n_steps, threads):
     """Time `n_steps` guided reverse steps of the CPU oracle at the bench shapes; returns rows/s for a T-step chain."""
     import numpy as np
@@ -96,6 +112,27 @@ def cpu_baseline(n_num, n_clusters, T, batch, n_steps, threads):
         chain.conditional_sample(tb, T, p, n_num, grad_fn, nz, steps=n_steps)
         dt = time.perf_counter() - t0
     return batch / (dt / n_steps * T), dt
+
+
+def train_cpu_baseline(n_num, T, batch, n_steps, threads):
+    """`n_steps` training steps of the CPU oracle (oracle.trainer.run_loop: mixed_loss, autograd backward, AdamW, EMA - the
+    reference's loop, scripts/train.py:30-71) at the bench shape; returns steps/s."""
+    from oracle import schedule, trainer
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from weights import mlp_shapes, seeded_state
+    torch.set_num_threads(threads)
+    tb = schedule.tables("cosine", T)
+    p = seeded_state(mlp_shapes(n_num, DENOISER_LAYERS), 1)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda: {"t": torch.randint(0, T, (batch,), generator=g), "noise": torch.randn(batch, n_num, generator=g), "u": None}
+    xs = [torch.randn(batch, n_num, generator=g) for _ in range(n_steps + 1)]
+    draws = [mk() for _ in range(n_steps + 1)]
+    trainer.run_loop(tb, T, p, xs[:1], draws[:1], n_num, [], 6e-4, 1e-5, 10 ** 6)
+    p = {k: v.detach() for k, v in p.items()}
+    t0 = time.perf_counter()
+    trainer.run_loop(tb, T, p, xs[1:], draws[1:], n_num, [], 6e-4, 1e-5, 10 ** 6)
+    dt = time.perf_counter() - t0
+    return n_steps / dt, dt
 
 
 def train_bench(device, n_num, T, batch, steps, warmup, barrier):
@@ -391,9 +428,11 @@ def main():
         dom = "gemm_f16x3_256x320" if args.gemm == "f16x3" else "gemm_f32_nt_128x128"
         if dom in families:
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_r01_f16x3.json" if args.gemm == "f16x3" else "traffic_r01.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            for rnd in ("r02", "r01"):                       # newest committed PMC measurement of this kernel
+                tpath = os.path.join(ROOT, "profiles", f"traffic_{rnd}_f16x3.json" if args.gemm == "f16x3" else f"traffic_{rnd}.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                    break
             f = families[dom]
             fi = names.index(dom)
             if args.gemm == "f16x3":
@@ -408,6 +447,7 @@ def main():
                             "all_f16x3_layers_tflops": round(all_tf, 2),
                             "achieved": round(f["tflops"], 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(f["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
+                            "frac_of_split_ceiling": round(3.0 * f["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
                             "mfma_issue_frac": round(3.0 * f["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
                             "vs_f32_matrix_peak": round(f["tflops"] / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
                             "avg_launch_us": round(f["avg_us"], 2), "launches_timed": f["launches"],
@@ -428,6 +468,14 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             train["ms_per_step"] = round(float(tm.item()), 3)
             train["steps_per_s"] = round(1e3 / float(tm.item()), 2)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            share = cpu_share()
+            v, dtc = train_cpu_baseline(args.n_num, T, 4096, 10, share)
+            v1, dt1 = train_cpu_baseline(args.n_num, T, 4096, 3, 1)
+            train["cpu_baseline"] = {"value": round(v, 3), "unit": "steps/s", "cores": share, "kind": "port",
+                                     "sample": f"10 oracle training steps at B 4096 ({dtc:.1f} s)",
+                                     "one_thread": {"value": round(v1, 3), "cores": 1, "sample": f"3 steps ({dt1:.1f} s)"},
+                                     "cores_visible": os.cpu_count()}
 
     trace("training leg done")
     # the same chain on the float32-input MFMA kernels (one chain, after the timed region): the exact-f32 reference point
@@ -509,12 +557,19 @@ def main():
         out["kernel_families"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                                       "tflops": round(v["tflops"], 2), "gbps": round(v["gbps"], 1)} for k, v in families.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        threads = cpu_share()
         cb = min(B, 20000)
         v, dt = cpu_baseline(args.n_num, args.clusters, T, cb, args.cpu_steps, threads)
+        n1 = max(2, args.cpu_steps // 10)
+        v1, dt1 = cpu_baseline(args.n_num, args.clusters, T, cb, n1, 1)
+        torch.set_num_threads(threads)
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "rows/s", "cores": threads, "kind": "port",
                                "sample": f"{args.cpu_steps} guided reverse steps (t={T - 1}..{T - args.cpu_steps}) on {cb} rows, "
-                                         f"same networks; {dt:.1f} s of CPU work, extrapolated to {T} steps"}
+                                         f"same networks; {dt:.1f} s of CPU work, extrapolated to {T} steps",
+                               "one_thread": {"value": round(v1, 2), "cores": 1, "sample": f"{n1} steps, {dt1:.1f} s"},
+                               "cores_visible": os.cpu_count(),
+                               "note": "cores = this process's CPU share (sched affinity, capped by the box's OMP_NUM_THREADS); "
+                                       "os.cpu_count() on the GPU box counts the whole multi-GPU machine"}
         out["speedup_vs_cpu"] = round(value / v, 1)
     if rank == 0:
         print(json.dumps(out))
