@@ -213,8 +213,7 @@ class ClassifierTrainer:
         # data parallel (every rank must construct the trainer and call step()): parameters broadcast once, one all-reduce
         # of the flat gradient per step.  data_parallel=False keeps a trainer local to its rank (per-relation sharding,
         # parallel.assign_relations: each rank trains other classifiers).
-        if (data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized()
-                and torch.distributed.get_world_size() > 1):
+        if data_parallel and _par.data_parallel_active():
             self.dist = torch.distributed
             self.world = self.dist.get_world_size()
             _par.broadcast_(self.flat, src=0)

@@ -93,6 +93,66 @@ def gmm_mstep(X, log_resp, log_prob_norm=None, reg_covar=1e-6, workspace=None):
     return out
 
 
+def mstep_totals_size(k, d):
+    f = lib().clava_gmm_mstep_totals_doubles
+    f.restype = ctypes.c_longlong
+    return int(f(c_int(k), c_int(d)))
+
+
+def gmm_mstep_partial(X, log_resp, log_prob_norm=None, workspace=None, out=None):
+    """This shard's M-step sums (`clava_gmm_mstep_partial_f64`): one float64 device tensor of `mstep_totals_size(k, d)`
+    doubles, layout in include/clava_hip.h (`unpack_mstep_totals` gives views).  Sum the tensors of all row shards, then
+    `gmm_mstep_finalize`."""
+    _lib.require_cuda(X, log_resp)
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    log_resp = log_resp.contiguous()
+    N, d = X.shape
+    k = log_resp.shape[1]
+    E = mstep_totals_size(k, d)
+    if workspace is None:
+        workspace = torch.empty(512 * E, device=X.device, dtype=torch.float64)
+    if out is None:
+        out = torch.empty(E, device=X.device, dtype=torch.float64)
+    if N == 0:
+        return out.zero_()
+    check(lib().clava_gmm_mstep_partial_f64(ptr(X), c_ll(X.stride(0)), c_ll(N), c_int(d), c_int(k), ptr(log_resp), ptr(log_prob_norm),
+                                            ptr(workspace), ptr(out), stream_ptr()), "clava_gmm_mstep_partial_f64")
+    return out
+
+
+def gmm_mstep_finalize(totals, n_rows, k, d, reg_covar=1e-6):
+    """Parameters from summed totals (`clava_gmm_mstep_finalize_f64`); `n_rows` = rows of ALL shards.  Returns the packed
+    tensor `gmm_mstep` returns."""
+    _lib.require_cuda(totals)
+    if totals.numel() != mstep_totals_size(k, d) or totals.dtype != torch.float64:
+        raise _lib.ClavaHipError("gmm_mstep_finalize: totals must hold mstep_totals_size(k, d) float64 values")
+    out = torch.empty(2 + k + 3 * k * d, device=totals.device, dtype=torch.float64)
+    st, w, m, cv, pc = unpack_mstep(out, k, d)
+    check(lib().clava_gmm_mstep_finalize_f64(ptr(totals), c_ll(int(n_rows)), c_int(d), c_int(k), ctypes.c_double(reg_covar), ptr(w), ptr(m),
+                                             ptr(cv), ptr(pc), ptr(st), stream_ptr()), "clava_gmm_mstep_finalize_f64")
+    return out
+
+
+def unpack_mstep_totals(buf, k, d):
+    """(sum resp*x [k,d], sum resp*x^2 [k,d], sum resp [k], sum log_prob_norm []) views of a totals buffer (host or device)."""
+    KP, DP = (k + 15) // 16 * 16, (d + 31) // 32 * 32
+    sx = buf[:KP * DP].reshape(KP, DP)[:k, :d]
+    sxx = buf[KP * DP:2 * KP * DP].reshape(KP, DP)[:k, :d]
+    return sx, sxx, buf[2 * KP * DP:2 * KP * DP + k], buf[2 * KP * DP + KP]
+
+
+def pack_mstep_totals(sx, sxx, nk, lpn_sum):
+    """Inverse of `unpack_mstep_totals` for host arrays (tests: oracle totals in the library's layout)."""
+    k, d = sx.shape
+    KP, DP = (k + 15) // 16 * 16, (d + 31) // 32 * 32
+    buf = torch.zeros(2 * KP * DP + KP + 1, dtype=torch.float64)
+    a, b, c, _ = unpack_mstep_totals(buf, k, d)
+    a.copy_(torch.as_tensor(sx)); b.copy_(torch.as_tensor(sxx)); c.copy_(torch.as_tensor(nk))
+    buf[2 * KP * DP + KP] = float(lpn_sum)
+    return buf
+
+
 def unpack_mstep(buf, k, d):
     """(stats [2], weights [k], means [k,d], covariances [k,d], precisions_chol [k,d]) views of a packed M-step result."""
     o = 2

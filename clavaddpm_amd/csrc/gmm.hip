@@ -654,11 +654,14 @@ long long clava_gmm_mstep_workspace_doubles(int k, int d) {
     return (512 + 1) * (2 * KP * DP + KP + 1) + 2;
 }
 
-int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
-                        const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
-                        double* covariances, double* precisions_chol, double* stats, void* stream) {
-    CLAVA_CHECK_ARG(X && log_resp && workspace && weights && means && covariances && precisions_chol && stats,
-                    "gmm_mstep: null argument");
+long long clava_gmm_mstep_totals_doubles(int k, int d) {
+    const long long KP = (k + 15) / 16 * 16, DP = (d + 31) / 32 * 32;
+    return 2 * KP * DP + KP + 1;
+}
+
+int clava_gmm_mstep_partial_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
+                                const double* log_prob_norm, double* workspace, double* totals, void* stream) {
+    CLAVA_CHECK_ARG(X && log_resp && workspace && totals, "gmm_mstep: null argument");
     CLAVA_CHECK_ARG(N > 0 && d > 0 && k > 0 && ldx >= d, "gmm_mstep: bad shape N=%lld d=%d k=%d", N, d, k);
     if (k > KMAX) {
         clava_set_error("gmm_mstep: k=%d components exceeds the supported maximum of %d", k, KMAX);
@@ -675,11 +678,6 @@ int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int 
     long long G = (groups + 3) / 4;
     if (G > 512) G = 512;
     if (G < 1) G = 1;
-    double* totals = workspace + (size_t)512 * g.set_stride;
-    if (hipMemsetAsync(stats, 0, 2 * sizeof(double), st) != hipSuccess) {
-        clava_set_error("gmm_mstep: hipMemsetAsync failed");
-        return CLAVA_ERR_LAUNCH;
-    }
     {
         ProfScope prof(PROF_GMM, 4.0 * N * d * k, 8.0 * N * (d + (double)k * chunks + 1), st);
         switch (CT) {
@@ -693,10 +691,38 @@ int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int 
     const long long E = g.set_stride;
     hipLaunchKernelGGL(gmm_mstep_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, g.part, g.set_stride, (int)G, E, totals);
     CLAVA_CHECK_LAUNCH("clava_gmm_mstep_f64(reduce)");
-    hipLaunchKernelGGL(gmm_mstep_params_kernel, dim3(k), dim3(128), 0, st, totals, g.KP, g.DP, k, d, N, reg_covar, weights, means,
+    return CLAVA_OK;
+}
+
+int clava_gmm_mstep_finalize_f64(const double* totals, long long N, int d, int k, double reg_covar, double* weights,
+                                 double* means, double* covariances, double* precisions_chol, double* stats, void* stream) {
+    CLAVA_CHECK_ARG(totals && weights && means && covariances && precisions_chol && stats, "gmm_mstep: null argument");
+    CLAVA_CHECK_ARG(N > 0 && d > 0 && k > 0, "gmm_mstep: bad shape N=%lld d=%d k=%d", N, d, k);
+    if (k > KMAX) {
+        clava_set_error("gmm_mstep: k=%d components exceeds the supported maximum of %d", k, KMAX);
+        return CLAVA_ERR_LIMIT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, 2 * sizeof(double), st) != hipSuccess) {
+        clava_set_error("gmm_mstep: hipMemsetAsync failed");
+        return CLAVA_ERR_LAUNCH;
+    }
+    const int KP = (k + 15) / 16 * 16, DP = (d + 31) / 32 * 32;
+    hipLaunchKernelGGL(gmm_mstep_params_kernel, dim3(k), dim3(128), 0, st, totals, KP, DP, k, d, N, reg_covar, weights, means,
                        covariances, precisions_chol, stats);
     CLAVA_CHECK_LAUNCH("clava_gmm_mstep_f64(params)");
     return CLAVA_OK;
+}
+
+int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
+                        const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
+                        double* covariances, double* precisions_chol, double* stats, void* stream) {
+    CLAVA_CHECK_ARG(X && log_resp && workspace && weights && means && covariances && precisions_chol && stats,
+                    "gmm_mstep: null argument");
+    double* totals = workspace ? workspace + (size_t)512 * clava_gmm_mstep_totals_doubles(k, d) : nullptr;
+    const int rc = clava_gmm_mstep_partial_f64(X, ldx, N, d, k, log_resp, log_prob_norm, workspace, totals, stream);
+    if (rc != CLAVA_OK) return rc;
+    return clava_gmm_mstep_finalize_f64(totals, N, d, k, reg_covar, weights, means, covariances, precisions_chol, stats, stream);
 }
 
 }  // extern "C"

@@ -63,7 +63,7 @@ class Trainer:
         self._flatten()
         self.world = 1
         self.dist = None
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if _par.data_parallel_active():       # not inside parallel.independent_ranks() (relation-parallel training)
             self.dist = torch.distributed
             self.world = self.dist.get_world_size()
             _par.broadcast_(self.flat, src=0)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 101
+#define CLAVA_HIP_VERSION 102
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
@@ -409,6 +409,19 @@ long long clava_gmm_mstep_workspace_doubles(int k, int d);
 int clava_gmm_mstep_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
                         const double* log_prob_norm, double reg_covar, double* workspace, double* weights, double* means,
                         double* covariances, double* precisions_chol, double* stats, void* stream);
+
+/* The same M-step in two halves, for mixtures whose rows are sharded over GPUs ("GMM M-step sufficient
+ * statistics all-reduce"; scikit-learn's `_estimate_gaussian_parameters` sums over ALL rows).  `partial` writes this
+ * shard's sums to totals[clava_gmm_mstep_totals_doubles(k, d)] (layout with KP = round_up(k,16), DP = round_up(d,32):
+ * sum_n resp*x at [c*DP + j], sum_n resp*x^2 at [(KP + c)*DP + j], sum_n resp at [2*KP*DP + c], sum_n log_prob_norm at
+ * [2*KP*DP + KP]; padding is zero); the caller adds the totals of all shards (one RCCL sum all-reduce) and `finalize`
+ * turns them into parameters with N = the row count of ALL shards.  clava_gmm_mstep_f64 is partial + finalize.
+ * `workspace` holds 512 * clava_gmm_mstep_totals_doubles(k, d) doubles for `partial`. */
+long long clava_gmm_mstep_totals_doubles(int k, int d);
+int clava_gmm_mstep_partial_f64(const double* X, long long ldx, long long N, int d, int k, const double* log_resp,
+                                const double* log_prob_norm, double* workspace, double* totals, void* stream);
+int clava_gmm_mstep_finalize_f64(const double* totals, long long N, int d, int k, double reg_covar, double* weights,
+                                 double* means, double* covariances, double* precisions_chol, double* stats, void* stream);
 
 /* ---- k-means++ seeding on the device ------------------------------------------------------------------
  * The N-sized arithmetic of scikit-learn's `_kmeans_plusplus` (sklearn/cluster/_kmeans.py), which seeds

@@ -45,6 +45,25 @@ def mstep(X, log_resp, reg_covar=1e-6):
     return weights, means, cov, 1.0 / np.sqrt(cov)
 
 
+def mstep_totals(X, log_resp, log_prob_norm=None):
+    """The sums `_estimate_gaussian_parameters` takes over rows, for ONE shard of the rows: (sum resp [k], sum resp*x
+    [k,d], sum resp*x^2 [k,d], sum log_prob_norm).  Adding the tuples of all shards and calling `mstep_from_totals` is
+    the row-sharded M-step."""
+    resp = np.exp(log_resp)
+    lp = 0.0 if log_prob_norm is None else float(np.sum(log_prob_norm))
+    return resp.sum(axis=0), np.dot(resp.T, X), np.dot(resp.T, X * X), lp
+
+
+def mstep_from_totals(nk_sum, sx, sxx, reg_covar=1e-6):
+    """`mstep` from the summed totals of all shards; same returns."""
+    nk = nk_sum + 10 * np.finfo(np.float64).eps
+    means = sx / nk[:, None]
+    cov = sxx / nk[:, None] - means ** 2 + reg_covar
+    if np.any(cov <= 0.0):
+        raise ValueError("ill-defined empirical covariance")
+    return nk / nk.sum(), means, cov, 1.0 / np.sqrt(cov)
+
+
 def em(X, weights, means, precisions_chol, tol=1e-4, max_iter=100, reg_covar=1e-6):
     """The EM loop of `BaseMixture.fit_predict` (`sklearn/mixture/_base.py`) from given initial parameters, n_init = 1:
     E-step, M-step, lower bound = mean log_prob_norm, stop when its change is below `tol`; then the final E-step.

@@ -130,6 +130,38 @@ def test_gmm_mstep_is_bitwise_reproducible_and_flags_bad_covariances():
         HipGaussianMixture(n_components=3, covariance_type="diag", reg_covar=0.0, random_state=0).fit(X[:2000])
 
 
+@pytest.mark.parametrize("N,d,k,cuts", [(1000, 5, 3, (0, 400, 1000)), (20001, 33, 50, (0, 1, 9000, 9000, 20001)), (300, 70, 64, (0, 300))])
+def test_row_sharded_mstep_totals_sum_to_the_single_call(N, d, k, cuts):
+    """per-shard sums (`clava_gmm_mstep_partial_f64`), added (what the RCCL sum all-reduce in
+    parallel.gmm_mstep_allreduce does; one rank here), finalised with the global row count - against the one-call M-step
+    and the numpy oracle; a shard with zero rows contributes zeros; world 1 goes through the same entry points."""
+    from clavaddpm_amd import clustering as cl, parallel
+    rng = np.random.RandomState(N + d)
+    X = rng.standard_normal((N, d)) * 2.0
+    lr_ = rng.standard_normal((N, k))
+    lr_ -= np.log(np.exp(lr_).sum(1, keepdims=True))
+    lpn = rng.standard_normal(N)
+    Xd, ld, pd_ = (torch.from_numpy(a).to(DEV) for a in (X, lr_, lpn))
+    tot = torch.zeros(cl.mstep_totals_size(k, d), device=DEV, dtype=torch.float64)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        tot += cl.gmm_mstep_partial(Xd[a:b], ld[a:b], pd_[a:b])
+    sx, sxx, nk, lp = cl.unpack_mstep_totals(tot.cpu(), k, d)
+    o_nk, o_sx, o_sxx, o_lp = ogmm.mstep_totals(X, lr_, lpn)
+    np.testing.assert_allclose(sx.numpy(), o_sx, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(sxx.numpy(), o_sxx, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(nk.numpy(), o_nk, rtol=1e-12)
+    assert abs(float(lp) - o_lp) < 1e-9
+    st, w, m, cv, pc = cl.unpack_mstep(cl.gmm_mstep_finalize(tot, N, k, d).cpu(), k, d)
+    st1, w1, m1, cv1, pc1 = cl.unpack_mstep(cl.gmm_mstep(Xd, ld, pd_).cpu(), k, d)
+    want = ogmm.mstep(X, lr_)
+    for got, one, ora in zip((w, m, cv, pc), (w1, m1, cv1, pc1), want):
+        np.testing.assert_allclose(got.numpy(), ora, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(got.numpy(), one.numpy(), rtol=1e-10, atol=1e-11)
+    assert abs(float(st[0]) - lpn.mean()) < 1e-12 and float(st[1]) == 0.0
+    alone = cl.unpack_mstep(parallel.gmm_mstep_allreduce(Xd, ld, pd_).cpu(), k, d)       # no process group: one shard
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(alone, (st1, w1, m1, cv1, pc1)))
+
+
 def test_g11_device_em_loop_matches_sklearn_run():
     """`fit` with E-step, M-step and lower bound on the device against scikit-learn's own run (recorded in G11): same
     number of EM iterations, parameters to 1e-8, identical cluster labels."""

@@ -19,7 +19,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), n
-    assert L.clava_version() == 101
+    assert L.clava_version() == 102
     assert L.clava_device_count() >= 0            # host-only probe; no compute call without a GPU
 
 
@@ -145,6 +145,84 @@ def test_gather_and_gradient_average_world_size_2_gloo():
         assert rows == [float(i) for i in range(11)]           # rank order, ragged slices (6 + 5)
         assert eshape == (2, 3)                                # a rank with zero rows still takes part
         assert g == [1.5] * 5                                  # mean of (1, 2)
+
+
+BERKA = [(None, "district"), ("district", "account"), ("district", "client"), ("account", "loan"), ("account", "order"),
+         ("account", "trans"), ("account", "disp"), ("disp", "card")]
+BERKA_ROWS = [77, 4500, 5369, 682, 6471, 1056320, 5369, 892]
+
+
+def _gloo_worker_mstep_relations(rank, world, port, q, tmpdir):
+    """Rank body: (1) the row-sharded M-step - every rank reduces its own rows with the oracle, the library-layout totals
+    and row counts are summed by parallel.allreduce_mstep_totals_, parameters are finalised from the sums; (2) the
+    relation-parallel training driver with stub trainers, with and without a checkpoint directory."""
+    import numpy as np
+    import torch.distributed as dist
+    from clavaddpm_amd import clustering
+    from oracle import gmm as ogmm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(5)
+        N, d, k = 1001, 5, 7
+        X = rng.standard_normal((N, d)) * 2.0
+        lr_ = rng.standard_normal((N, k))
+        lr_ -= np.log(np.exp(lr_).sum(1, keepdims=True))
+        lpn = rng.standard_normal(N)
+        a, b = parallel.row_slice(N, rank, world)
+        nk, sx, sxx, lp = ogmm.mstep_totals(X[a:b], lr_[a:b], lpn[a:b])
+        tot = clustering.pack_mstep_totals(sx, sxx, nk, lp)
+        tot, n_all = parallel.allreduce_mstep_totals_(tot, b - a)
+        sx2, sxx2, nk2, lp2 = clustering.unpack_mstep_totals(tot, k, d)
+        got = ogmm.mstep_from_totals(nk2.numpy(), sx2.numpy(), sxx2.numpy())
+        want = ogmm.mstep(X, lr_)
+        err = max(float(np.abs(g - w_).max()) for g, w_ in zip(got, want))
+        mstep_ok = (n_all == N, err < 1e-12, abs(float(lp2) / n_all - lpn.mean()) < 1e-12)
+
+        cost = dict(zip(BERKA, BERKA_ROWS))
+        seen = []
+
+        def stub_train(parent, child):
+            seen.append((parent, child))
+            assert not parallel.data_parallel_active()      # trainers built here must not all-reduce
+            return {"relation": (parent, child), "trained_by": rank}
+
+        assert parallel.data_parallel_active()
+        models = parallel.train_relations(BERKA, stub_train, save_dir=None, cost=cost)
+        in_order = list(models.keys()) == BERKA
+        by = {rel: m["trained_by"] for rel, m in models.items()}
+        plan = parallel.assign_relations(BERKA, world, cost)
+        planned = all(by[rel] == r for r, rels in plan.items() for rel in rels) and seen == plan[rank]
+        # with a checkpoint directory: results travel as files; a second pass finds every checkpoint and trains nothing
+        models_f = parallel.train_relations(BERKA, stub_train, save_dir=tmpdir, cost=cost)
+        n_seen = len(seen)
+        models_f2 = parallel.train_relations(BERKA, stub_train, save_dir=tmpdir, cost=cost)
+        files_ok = (models_f == models and models_f2 == models and len(seen) == n_seen
+                    and sorted(os.listdir(os.path.join(tmpdir, "models"))) == sorted(f"{p}_{c}_ckpt.pkl" for p, c in BERKA))
+        q.put((rank, mstep_ok, in_order, planned, files_ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mstep_allreduce_and_relation_training_world_size_2_gloo(tmp_path):
+    """GMM M-step sufficient statistics all-reduce, and berka's per-relation training (complex_pipeline.py:59-84)
+    spread over ranks - the reduction / assignment / exchange logic on two gloo ranks (the device halves are covered by
+    the -m gpu tests)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker_mstep_relations, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, mstep_ok, in_order, planned, files_ok in out:
+        assert all(mstep_ok), (rank, mstep_ok)
+        assert in_order and planned and files_ok, (rank, in_order, planned, files_ok)
 
 
 def test_relations_are_assigned_to_ranks_deterministically():
