@@ -19,10 +19,20 @@
 //   v_mfma_f32_16x16x32_f16: lane l supplies row (l & 15), k = 8 * (l >> 4) .. +7 of both operands.
 //   BM is chosen per shape so that the tile count fills the 256 CUs in whole rounds (M = 20000 sampling batches).
 #include "split.h"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef CLAVA_GEMM_STAMPS
+// Diagnostic build only (tools/build_variant.py stamps gemm_f16x3.hip -DCLAVA_GEMM_STAMPS; never in the shipped library):
+// per workgroup x wave {loop cycles, cycles parked at the closing wait + barrier, loop time in 100 MHz ticks, k blocks}
+__device__ unsigned long long g_gemm_stamps[4096 * 8 * 8];
+extern "C" int clava_debug_gemm_stamps_(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 namespace {
 
@@ -33,12 +43,12 @@ __device__ __forceinline__ void glds16(const char* src, char* dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
 }
 
-template <int BN, int BM, int WN, int NS>
-__global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
-    constexpr int WM = 8 / WN;
+template <int BN, int BM, int WN, int NS, int NW = 8, int OCC = 1>
+__global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs g) {
+    constexpr int WM = NW / WN;                               // NW waves: WN along n x WM along m (8 / NW workgroups share a CU)
     constexpr int TN = BN / (16 * WN), TM = BM / (16 * WM);   // 16x16 MFMA tiles per wave
     constexpr int G = (BN + BM) / 8;                          // 8-row staging groups per stage (one LDS-DMA each)
-    constexpr int Q = (G + 7) / 8;                            // groups per wave (the last one may be absent)
+    constexpr int Q = (G + NW - 1) / NW;                      // groups per wave (the last one may be absent)
     constexpr int STAGE = (BN + BM) * 128;
     constexpr int SPREAD = TN >= 2 ? TN / 2 : 1;             // MFMA groups over which a stage's LDS-DMA issue is spread
     static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS stages");
@@ -48,6 +58,9 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
+#ifdef CLAVA_GEMM_STAMPS
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // XCD-aware tile order (blocks with equal blockIdx % 8 share an XCD and take a contiguous run of tiles: the
     // column tiles of one activation row panel); bijective for any tile count
@@ -66,6 +79,18 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
         g.out_f32 += (long long)blockIdx.y * g.slab_stride;
     }
 
+    // ---- bias sums of this tile's columns (tile-local order, zero beyond N), read back by the epilogue
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
+    for (int c = tid; c < BN; c += 64 * NW) {
+        const int n = n0 + c;
+        float b = 0.f;
+        if (n < g.N) {
+            if (g.bias) b += g.bias[n];
+            if (g.bias2) b += g.bias2[n];
+        }
+        bias_s[c] = b;
+    }
+
     // ---- staging sources: lane i of a group fills LDS row 8*group + (i >> 3), chunk slot (i & 7).  Every wave issues
     // exactly Q DMAs per stage (a wave without a last group re-issues its previous one: same source, same destination)
     // so that the counted vmcnt waits below mean the same thing in every wave.
@@ -73,10 +98,10 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     int dst[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int qq = (wave + 8 * q < G) ? q : q - 1;
-        const int r = (wave + 8 * qq) * 8 + (lane >> 3);
+        const int qq = (wave + NW * q < G) ? q : q - 1;
+        const int r = (wave + NW * qq) * 8 + (lane >> 3);
         const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 4;
-        dst[q] = qq * 8192;
+        dst[q] = qq * NW * 1024;
         if (r < BN) {
             // LDS row 32*p + 16*b + 4*q + rr holds output column 32*p + 8*q + 4*b + rr (epilogue: 8 consecutive columns per lane)
             const int pr = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
@@ -115,18 +140,27 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
 
     int cur = 0, nxt = (NS - 1) * STAGE;                     // byte offsets of the stage read now / filled now
+#ifdef CLAVA_GEMM_STAMPS
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_bar = 0, st_a = 0, st_b = 0;
+#endif
     for (int kb = 0; kb < nkb; ++kb) {
-        const bool more = kb + NS - 1 < nkb;
-        const int ko = (kb + NS - 1) * 128;
+        // branch-free body: in the tail (no block NS-1 ahead) the last block is fetched again into the stage nobody reads any
+        // more - one basic block lets the compiler place counted lgkmcnt waits instead of draining the LDS queue at a join
+        const int ko = min(kb + NS - 1, nkb - 1) * 128;
+        // fragment reads in the order the first MFMA group consumes them (wl x ah[j], then wh x al[j], wh x ah[j]): LDS
+        // returns data in issue order, so the first MFMAs start after two reads instead of after all 2*TM + 2
         h8 ah[TM], al[TM];
+        h8 wl = *reinterpret_cast<const h8*>(frW + cur + off_lo);
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            ah[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_hi);
-            al[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_lo);
-        }
+        for (int j = 0; j < TM; ++j) ah[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_hi);
         // W fragments are read one MFMA group ahead: the reads of group i+1 are in flight while group i multiplies
         h8 wh = *reinterpret_cast<const h8*>(frW + cur + off_hi);
-        h8 wl = *reinterpret_cast<const h8*>(frW + cur + off_lo);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) al[j] = *reinterpret_cast<const h8*>(frA + cur + j * 2048 + off_lo);
+#ifdef CLAVA_GEMM_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             h8 wh_n = wh, wl_n = wl;
@@ -136,114 +170,165 @@ __global__ void __launch_bounds__(512) gemm_f16x3_kernel(SplitGemmArgs g) {
             }
             // the DMA of the stage NS-1 blocks ahead is issued behind the fragment reads of the first half of the wave's
             // MFMA groups: its issue cost (~100 cycles per instruction) hides under MFMAs
-            if (more) {
 #pragma unroll
-                for (int q = 0; q < Q; ++q)
-                    if ((q * SPREAD) / Q == i) glds16(src[q] + ko, st + nxt + dst[q]);
-            }
+            for (int q = 0; q < Q; ++q)
+                if ((q * SPREAD) / Q == i) glds16(src[q] + ko, st + nxt + dst[q]);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[j], acc[i][j], 0, 0, 0);
             wh = wh_n; wl = wl_n;
         }
         // stage kb+1 must have landed (this wave's part) and every wave must be done reading stage kb before the next
         // iteration overwrites it; in the tail (nothing issued this iteration) the queue is simply drained
+#ifdef CLAVA_GEMM_STAMPS
+        st_bar += st_b - st_a;                                // previous block's wait (both values have long arrived)
+        st_a = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (NS == 2) {
             __syncthreads();      // two stages: the whole DMA queue is this stage; the compiler keeps rotating MFMAs across it
+#ifdef CLAVA_GEMM_STAMPS
+            st_b = __builtin_amdgcn_s_memtime();
+#endif
         } else {
-            if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(Q * (NS - 2)) : "memory");
         }
         nxt = cur;
         cur = (cur + STAGE == NS * STAGE) ? 0 : cur + STAGE;
     }
 
+#ifdef CLAVA_GEMM_STAMPS
+    if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+        unsigned long long* o = g_gemm_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = __builtin_amdgcn_s_memtime() - st_c0;
+        o[1] = st_bar + (st_b - st_a);
+        o[2] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        o[3] = nkb;
+        o[4] = st_k0;
+        o[5] = st_r0;
+        o[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tail's refetches must have landed before the workgroup's LDS is released
+
     // ---- epilogue.  W rows are staged permuted (see the staging sources): within every 32-column block, MFMA tile
     // b (0/1) row 4*q + r holds column 8*q + 4*b + r, so a lane's accumulators of an even/odd tile pair are 8
     // CONSECUTIVE columns of one output row: one 16-byte store per plane, and the four lanes of a row fill the row's
     // whole 128-byte block (64 B hi | 64 B lo).  Configurations with one tile per wave store 4 columns (8 bytes).
+    // The element arithmetic is branch-free (measured: with per-element tests of the argument flags and one bias load +
+    // wait per column the epilogue of a 256 x 320 tile took 15 us of a 96 us kernel, instruction-bound): the bias sums
+    // come from LDS (staged at kernel start), the activation is max(x, slope * x), the overflow test an integer maximum of
+    // |value| bit patterns, and the uniform flags (mask / which outputs) select one of six straight-line variants.
     constexpr int EW = (TN % 2 == 0) ? 8 : 4;               // columns per lane per store
     constexpr int EP = (TN % 2 == 0) ? TN / 2 : TN;         // stores per output row per plane
     const int Np = (g.N + 31) & ~31;
     const int m_lane = m0 + wm * (BM / WM) + lrow;
-    bool ovf = false;
+    const float slope = g.act == CLAVA_ACT_RELU ? 0.f : (g.act == CLAVA_ACT_LEAKY ? 0.01f : 1.f);
     // float32 rows that start 16-byte aligned take vector stores (nq is a multiple of EW)
     const bool f32_vec = g.out_f32 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f32) & 15) == 0;
+    unsigned amax = 0;                                       // max over stored split values of (bits of |value|): NaN > inf > finite
+
+    auto epilogue = [&](auto has_mask, auto out_mode) {
+        constexpr bool MASK = decltype(has_mask)::value;
+        constexpr bool SPLIT = decltype(out_mode)::value != 1, F32 = decltype(out_mode)::value != 0;
 #pragma unroll
-    for (int ip = 0; ip < EP; ++ip) {
-        const int it = wn * TN + (EW == 8 ? 2 * ip : ip);    // n-subtile index inside the workgroup tile
-        const int nq = n0 + 32 * (it >> 1) + 8 * kq + 4 * (it & 1);
-        if (nq >= Np) continue;
-        float bs[EW];
+        for (int ip = 0; ip < EP; ++ip) {
+            const int it = wn * TN + (EW == 8 ? 2 * ip : ip);    // n-subtile index inside the workgroup tile
+            const int nl = 32 * (it >> 1) + 8 * kq + 4 * (it & 1);
+            const int nq = n0 + nl;
+            if (nq >= Np) continue;
+            float bs[EW];
 #pragma unroll
-        for (int r = 0; r < EW; ++r) {
-            const int n = nq + r;
-            float b = 0.f;
-            if (n < g.N) {
-                if (g.bias) b += g.bias[n];
-                if (g.bias2) b += g.bias2[n];
-            }
-            bs[r] = b;
-        }
-        const long long col_off = (long long)(nq >> 5) * 128 + ((nq & 31) << 1);
+            for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(bs + r) = *reinterpret_cast<const f32x4*>(bias_s + nl + r);
+            const long long col_off = (long long)(nq >> 5) * 128 + ((nq & 31) << 1);
+            const bool inside = nq + EW <= g.N;
+            h8 mh8[TM];
+            h4 mh4[TM];
+            if constexpr (MASK) {                            // all of this column group's mask loads before the first store
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m_lane + j * 16;
-            if (m >= g.M) continue;
-            float v[EW];
-#pragma unroll
-            for (int r = 0; r < EW; ++r) {
-                const float a = (EW == 8) ? acc[2 * ip + (r >> 2)][j][r & 3] : acc[ip][j][r & 3];
-                float x = a * g.scale_acc + bs[r];
-                if (g.act == CLAVA_ACT_RELU) x = x > 0.f ? x : 0.f;
-                else if (g.act == CLAVA_ACT_LEAKY) x = x > 0.f ? x : 0.01f * x;
-                v[r] = x;
-            }
-            if (g.mask) {
-                const char* mp = g.mask + (long long)m * g.pitchMask + col_off;
-                _Float16 mh[EW];
-                if constexpr (EW == 8) *reinterpret_cast<h8*>(mh) = *reinterpret_cast<const h8*>(mp);
-                else *reinterpret_cast<h4*>(mh) = *reinterpret_cast<const h4*>(mp);
-#pragma unroll
-                for (int r = 0; r < EW; ++r) v[r] *= ((float)mh[r] > 0.f) ? 1.f : g.mask_slope;
+                for (int j = 0; j < TM; ++j) {
+                    const int m = min(m_lane + j * 16, g.M - 1);
+                    const char* mp = g.mask + (long long)m * g.pitchMask + col_off;
+                    if constexpr (EW == 8) mh8[j] = *reinterpret_cast<const h8*>(mp);
+                    else mh4[j] = *reinterpret_cast<const h4*>(mp);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < EW; ++r) v[r] = (nq + r < g.N) ? v[r] * g.alpha : 0.f;
-            if (g.out_split) {
-                _Float16 hi[EW], lo[EW];
+            for (int j = 0; j < TM; ++j) {
+                const int m = m_lane + j * 16;
+                if (m >= g.M) continue;
+                float v[EW];
 #pragma unroll
                 for (int r = 0; r < EW; ++r) {
-                    const float sc = v[r] * g.scale_out;
-                    ovf |= !(fabsf(sc) <= 65504.f);
-                    hi[r] = (_Float16)sc;
-                    lo[r] = (_Float16)(sc - (float)hi[r]);
+                    const float a = (EW == 8) ? acc[2 * ip + (r >> 2)][j][r & 3] : acc[ip][j][r & 3];
+                    const float x = a * g.scale_acc + bs[r];
+                    v[r] = fmaxf(x, x * slope);              // relu (slope 0), leaky relu (0.01), identity (1)
                 }
-                char* op = g.out_split + (long long)m * g.pitchOut + col_off;
-                if constexpr (EW == 8) {
-                    *reinterpret_cast<h8*>(op) = *reinterpret_cast<const h8*>(hi);
-                    *reinterpret_cast<h8*>(op + 64) = *reinterpret_cast<const h8*>(lo);
-                } else {
-                    *reinterpret_cast<h4*>(op) = *reinterpret_cast<const h4*>(hi);
-                    *reinterpret_cast<h4*>(op + 64) = *reinterpret_cast<const h4*>(lo);
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int r = 0; r < EW; ++r) {
+                        const float mv = (EW == 8) ? (float)mh8[j][r] : (float)mh4[j][r];
+                        v[r] *= (mv > 0.f) ? 1.f : g.mask_slope;
+                    }
                 }
-            }
-            if (g.out_f32) {
-                float* cp = g.out_f32 + (long long)m * g.ldc + nq;
-                if (f32_vec && nq + EW <= g.N) {             // 16-byte stores: a lane's EW consecutive columns of one row
 #pragma unroll
-                    for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(cp + r) = f32x4{v[r], v[r + 1], v[r + 2], v[r + 3]};
-                } else {
+                for (int r = 0; r < EW; ++r) v[r] *= g.alpha;
+                if (!inside) {
 #pragma unroll
-                    for (int r = 0; r < EW; ++r)
-                        if (nq + r < g.N) cp[r] = v[r];
+                    for (int r = 0; r < EW; ++r) v[r] = (nq + r < g.N) ? v[r] : 0.f;
+                }
+                if constexpr (SPLIT) {
+                    _Float16 hi[EW], lo[EW];
+#pragma unroll
+                    for (int r = 0; r < EW; ++r) {
+                        const float sc = v[r] * g.scale_out;
+                        amax = max(amax, __float_as_uint(sc) << 1);
+                        hi[r] = (_Float16)sc;
+                        lo[r] = (_Float16)(sc - (float)hi[r]);
+                    }
+                    char* op = g.out_split + (long long)m * g.pitchOut + col_off;
+                    if constexpr (EW == 8) {
+                        *reinterpret_cast<h8*>(op) = *reinterpret_cast<const h8*>(hi);
+                        *reinterpret_cast<h8*>(op + 64) = *reinterpret_cast<const h8*>(lo);
+                    } else {
+                        *reinterpret_cast<h4*>(op) = *reinterpret_cast<const h4*>(hi);
+                        *reinterpret_cast<h4*>(op + 64) = *reinterpret_cast<const h4*>(lo);
+                    }
+                }
+                if constexpr (F32) {
+                    float* cp = g.out_f32 + (long long)m * g.ldc + nq;
+                    if (f32_vec && inside) {                 // 16-byte stores: a lane's EW consecutive columns of one row
+#pragma unroll
+                        for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(cp + r) = f32x4{v[r], v[r + 1], v[r + 2], v[r + 3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < EW; ++r)
+                            if (nq + r < g.N) cp[r] = v[r];
+                    }
                 }
             }
         }
+    };
+    using std::integral_constant;
+    const int mode = g.out_split ? (g.out_f32 ? 2 : 0) : 1;
+    if (g.mask) {
+        if (mode == 0) epilogue(integral_constant<bool, true>{}, integral_constant<int, 0>{});
+        else if (mode == 1) epilogue(integral_constant<bool, true>{}, integral_constant<int, 1>{});
+        else epilogue(integral_constant<bool, true>{}, integral_constant<int, 2>{});
+    } else {
+        if (mode == 0) epilogue(integral_constant<bool, false>{}, integral_constant<int, 0>{});
+        else if (mode == 1) epilogue(integral_constant<bool, false>{}, integral_constant<int, 1>{});
+        else epilogue(integral_constant<bool, false>{}, integral_constant<int, 2>{});
     }
-    if (ovf && g.overflow) *g.overflow = 1;
+    // |value| <= 65504 <=> bits(|value|) <= 0x477fe000; infinities and NaNs have larger patterns
+    if (amax > (0x477fe000u << 1) && g.overflow) *g.overflow = 1;
+#ifdef CLAVA_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have left the wave
+    if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0)
+        g_gemm_stamps[((size_t)blockIdx.x * 8 + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // float32 [rows][cols] (ld) -> split rows; one thread per 4 consecutive columns
@@ -334,10 +419,11 @@ inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintp
 
 // ---- tile configurations ---------------------------------------------------------------------------------------------
 struct TileCfg {
-    int bn, bm, ns;
+    int bn, bm, ns, nw;
     void (*kernel)(SplitGemmArgs);
 };
-#define CLAVA_CFG(BN, BM, WN, NS) {BN, BM, NS, gemm_f16x3_kernel<BN, BM, WN, NS>}
+#define CLAVA_CFG(BN, BM, WN, NS) {BN, BM, NS, 8, gemm_f16x3_kernel<BN, BM, WN, NS>}
+#define CLAVA_CFG4(BN, BM, WN, NS, OCC) {BN, BM, NS, 4, gemm_f16x3_kernel<BN, BM, WN, NS, 4, OCC>}
 const TileCfg kCfgs[] = {
     CLAVA_CFG(256, 320, 2, 2),   // 0: 144 KB LDS, 40 MFMA tiles per wave
     CLAVA_CFG(128, 96, 4, 2),    // 1: 128-wide layers at M = 20000 (209 tiles)
@@ -349,6 +435,9 @@ const TileCfg kCfgs[] = {
     CLAVA_CFG(64, 128, 2, 2),    // 7: narrow outputs (heads, logits, the input gradient)
     CLAVA_CFG(128, 80, 8, 4),    // 8, 9: four-stage twins of 6 and 7 for short contractions in a single round of tiles - the
     CLAVA_CFG(64, 128, 2, 4),    //       whole k range is in flight at once (one exposed load latency instead of one per k block)
+    CLAVA_CFG4(128, 160, 2, 2, 2),  // 10: four waves of 64 x 80, two workgroups per CU (their barriers are not in step)
+    CLAVA_CFG4(128, 320, 2, 2, 1),  // 11: four waves of 64 x 160
+    CLAVA_CFG4(256, 160, 2, 2, 1),  // 12: four waves of 128 x 80
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
@@ -357,7 +446,7 @@ bool g_attr_set[64][kNumCfgs] = {};   // per device: the LDS limit is a per-devi
 // Cost model, calibrated on MI355X with tools/bench_f16x3.py: a configuration's sustained rate on a full chip (TFLOP/s
 // algorithmic, K = 1024, M = 20000), the tiles of the most loaded CU run back to back, plus a fixed launch / prologue /
 // epilogue cost.  It reproduces the measured times of the sampling (M = 20000) and training (M = 4096) shapes to ~15 %.
-const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0, 0.0, 0.0};   // 8, 9: never picked by cost
+const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // 0: never picked by cost
 static_assert(sizeof(kRateTF) / sizeof(kRateTF[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one rate per configuration");
 
 int pick_cfg(int M, int N, int Kp) {
@@ -426,7 +515,7 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     const double flops = 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp);
     const double bytes = 4.0 * ((double)g.M * g.Kp + (double)g.N * g.Kp + (double)g.M * g.N);
     ProfScope prof(PROF_GEMM_F16X3 + cfg, flops, bytes, stream);
-    hipLaunchKernelGGL(tc.kernel, dim3(g.tiles_m * g.tiles_n, slabs), dim3(512), lds, stream, g);
+    hipLaunchKernelGGL(tc.kernel, dim3(g.tiles_m * g.tiles_n, slabs), dim3(64 * tc.nw), lds, stream, g);
     CLAVA_CHECK_LAUNCH("clava_gemm_f16x3");
     return CLAVA_OK;
 }
