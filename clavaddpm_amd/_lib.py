@@ -22,6 +22,11 @@ class ClavaHipError(RuntimeError):
     pass
 
 
+class SplitOverflowError(ClavaHipError):
+    """A tensor of the split-f16 training path left the float16 range since the last calibration (Trainer.run_loop
+    catches it and re-runs the window on the float32 kernels)."""
+
+
 def declared_symbols():
     """Names of every function include/clava_hip.h declares."""
     text = open(HEADER_PATH).read()

@@ -10,6 +10,9 @@ What differs by design:
     launches, 40 EMA launches);
   * no host synchronisation per step: the reference calls `.item()` twice per step (`:56-57`); here the running loss
     sums stay on the device and are read once every `log_every` steps;
+  * split-f16 overflow (csrc/split.h): the overflow flag of the hidden-block kernels is read once per calibration window
+    (200 steps); if it is raised, `run_loop` restores the snapshot it took at the window's start (parameters, EMA, Adam
+    moments, step counters, RNG states, loss sums) and re-runs the window's batches on the float32 kernels;
   * data parallelism (new): when torch.distributed is initialised, the flat gradient is averaged
     with one RCCL all-reduce per step; parameters are broadcast from rank 0 at construction.
 """
@@ -20,6 +23,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from .. import _lib
 from .. import parallel as _par
 from .. import training as _tr
 from .._lib import c_float, c_int, check, lib, ptr, stream_ptr
@@ -100,8 +104,12 @@ class Trainer:
         from .. import split_nets
         if split_nets.get_gemm_mode() != "f16x3" or len(self.diffusion._denoise_fn.mlp.blocks) < 2:
             return None
+        if getattr(self, "_force_f32", 0) > 0:
+            return None
         if getattr(self, "_split", None) is None:
-            self._split = _tr.SplitTrainState()
+            self._split = _tr.SplitTrainState(getattr(self, "split_period", 200))
+            if self.dist is not None:                  # every rank must take the same branch at a calibration
+                self._split.flag_reduce = _par.allreduce_max_
         return self._split
 
     def _anneal_lr(self, step):
@@ -190,15 +198,66 @@ class Trainer:
         zero = torch.zeros((), device=x.device)
         return (loss_multi if loss_multi is not None else zero), (loss_gauss if loss_gauss is not None else zero)
 
+    # ---- split-f16 overflow: snapshot at every calibration, replay of the window on the float32 kernels ---------------
+    def _snapshot(self, step, sums, curr_count):
+        dev = self.flat.device
+        return {"step": step, "flat": self.flat.clone(), "ema": self.ema_flat.clone(), "m": self.exp_avg.clone(),
+                "v": self.exp_avg_sq.clone(), "opt_step": self.opt_step, "lr": self.lr, "sums": sums.clone(), "count": curr_count,
+                "rows": len(self.loss_history), "rng_cpu": torch.get_rng_state(), "rng_dev": torch.cuda.get_rng_state(dev),
+                "batches": []}
+
+    def _restore(self, snap, sums):
+        self.flat.copy_(snap["flat"]); self.ema_flat.copy_(snap["ema"])
+        self.exp_avg.copy_(snap["m"]); self.exp_avg_sq.copy_(snap["v"])
+        self.opt_step, self.lr = snap["opt_step"], snap["lr"]
+        sums.copy_(snap["sums"])
+        self.loss_history = self.loss_history.iloc[:snap["rows"]].copy()
+        torch.set_rng_state(snap["rng_cpu"])
+        torch.cuda.set_rng_state(snap["rng_dev"], self.flat.device)
+        from .. import split_nets
+        split_nets.invalidate()
+        return snap["step"], snap["count"]
+
     def run_loop(self):
         step = 0
         dev = self.flat.device
         sums = torch.zeros(2, device=dev, dtype=torch.float64)     # running loss_multi * n, loss_gauss * n (on the device)
         curr_count = 0
+        self.overflow_recoveries = 0
+        snap = None                                                # start of the calibration window in progress
+        replay = []                                                # batches still to be re-run after an overflow
         while step < self.steps:
-            x, out_dict = next(self.train_iter)
-            out_dict = {'y': out_dict}
-            batch_loss_multi, batch_loss_gauss = self._run_step(x, out_dict)
+            if replay:
+                x, out_dict = replay.pop(0)
+            else:
+                x, out_dict = next(self.train_iter)
+                out_dict = {'y': out_dict}
+            st = self._split_state()                               # None on the float32 kernels (also while re-running a window)
+            pending = self._snapshot(step, sums, curr_count) if st is not None and st.due() else None   # this step calibrates
+            if snap is not None:
+                snap["batches"].append((x, out_dict))
+            try:
+                batch_loss_multi, batch_loss_gauss = self._run_step(x, out_dict)
+            except _lib.SplitOverflowError:
+                # the window that just ended ran with a tensor beyond the float16 range: go back to its start, run it on the
+                # float32 kernels, then run the step that detected it (which calibrates afresh)
+                if snap is None or len(snap["batches"]) < 2:
+                    raise
+                self.overflow_recoveries += 1
+                replay = list(snap["batches"])
+                step, curr_count = self._restore(snap, sums)
+                self._split.flag.zero_()
+                self._force_f32 = len(replay) - 1
+                self._graph = None
+                snap = None
+                continue
+            if pending is not None:
+                pending["batches"].append((x, out_dict))
+                snap = pending
+            if getattr(self, "_force_f32", 0) > 0:
+                self._force_f32 -= 1
+                if self._force_f32 == 0 and getattr(self, "_split", None) is not None:
+                    self._split.steps_since = self._split.period   # the window was re-run in float32: calibrate afresh next
             self._anneal_lr(step)
             curr_count += len(x)
             sums[0] += batch_loss_multi.double() * len(x)

@@ -131,7 +131,9 @@ class SplitTrainState:
     a float32 step: every `period`-th step runs entirely on the float32 kernels and records the largest magnitude of
     every weight, activation and gradient tensor; scales place those near 2^6 (activations, gradients) / 2^10
     (weights), i.e. a factor 1000 / 64 below the float16 limit, far more than anything moves in `period` steps at
-    training learning rates.  The device overflow flag is read at the same cadence; a raised flag is an error."""
+    training learning rates.  The device overflow flag is read at the same cadence; a raised flag raises
+    SplitOverflowError, which `Trainer.run_loop` answers by restoring its snapshot of the window's start and re-running
+    the window on the float32 kernels."""
 
     def __init__(self, period=200):
         self.period = period
@@ -139,6 +141,7 @@ class SplitTrainState:
         self.flag = None
         self.steps_since = None
         self.generation = 0       # bumped by every calibration: captured graphs bake the scales in
+        self.flag_reduce = None   # data parallel: max of the overflow flag over ranks (set by the Trainer)
         self.bufs = {}
 
     def due(self):
@@ -163,9 +166,9 @@ class SplitTrainState:
         n = len(ws)
         if self.flag is None:
             self.flag = torch.zeros(1, device=ws[0].device, dtype=torch.int32)
-        elif int(self.flag.item()) != 0:
-            raise _lib.ClavaHipError("split-f16 training: a tensor left the float16 range since the last calibration "
-                                     "(magnitudes grew by more than 60x within %d steps)" % self.period)
+        elif int((self.flag_reduce(self.flag.clone()) if self.flag_reduce is not None else self.flag).item()) != 0:
+            raise _lib.SplitOverflowError("split-f16 training: a tensor left the float16 range since the last calibration "
+                                          "(magnitudes grew by more than 60x within %d steps)" % self.period)
         zero = torch.zeros((), device=ws[0].device)
         stats = torch.stack([w.detach().abs().max() for w in ws] + [h.abs().max() for h in hs] +
                             [gs[l].abs().max() if gs[l] is not None else zero for l in range(n)] +

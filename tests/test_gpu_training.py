@@ -182,3 +182,49 @@ def test_training_reduces_loss_on_a_learnable_target():
     tr.run_loop()
     hist = tr.loss_history["gloss"].to_numpy()
     assert hist[-1] < 0.6 * hist[0], hist
+
+
+def test_split_overflow_reruns_the_window_on_the_float32_kernels():
+    """A raised split-f16 overflow flag no longer aborts training: `run_loop` restores the snapshot of
+    the window's start and re-runs the window's batches on the float32 kernels.  The flag is raised by hand in the middle
+    of the second window; the run must finish with the same number of logged rows, count one recovery, and end within
+    float32-vs-split rounding (amplified by AdamW: see test_g8) of a run that never overflowed - both runs see the same
+    batches and the same draws, because the snapshot carries the RNG states."""
+    from clavaddpm_amd import split_nets
+
+    def run(poke_at):
+        torch.manual_seed(0)
+        n_num = 6
+        net = MLPDiffusion(n_num, 0, "none", {"d_layers": [128, 256, 128], "dropout": 0.0}).to(DEV).train()
+        d = GaussianMultinomialDiffusion(np.array([0]), n_num, net, num_timesteps=100, device=torch.device(DEV)).to(DEV).train()
+        g = torch.Generator().manual_seed(5)
+        data = torch.randn(40, 512, n_num, generator=g)
+        state = {"i": 0}
+
+        def it():
+            while True:
+                i = state["i"]
+                state["i"] += 1
+                if i == poke_at:
+                    tr._split.flag.fill_(1)            # as if a kernel of this window had seen a value beyond 65504
+                yield data[i % 40], torch.zeros(512, dtype=torch.long)
+
+        tr = Trainer(d, it(), lr=1e-3, weight_decay=0.0, steps=30, device=torch.device(DEV))
+        tr.split_period = 8
+        tr.log_every = 5
+        tr.run_loop()
+        return tr, torch.cat([p.detach().flatten().cpu() for p in net.parameters()]), state["i"]
+
+    prev = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode("f16x3")
+    try:
+        tr_a, w_a, drawn_a = run(poke_at=13)           # window 2 = steps 9..17 (step 0 and 9 calibrate): detected at step 18
+        tr_b, w_b, drawn_b = run(poke_at=-1)
+    finally:
+        split_nets.set_gemm_mode(prev)
+    assert tr_a.overflow_recoveries == 1 and tr_b.overflow_recoveries == 0
+    assert drawn_a == drawn_b == 30                     # re-run batches come from the snapshot, not from the iterator
+    assert list(tr_a.loss_history["step"]) == list(tr_b.loss_history["step"]) == [5, 10, 15, 20, 25, 30]
+    assert np.allclose(tr_a.loss_history["gloss"].to_numpy(), tr_b.loss_history["gloss"].to_numpy(), atol=2e-3)
+    assert torch.isfinite(w_a).all()
+    assert float((w_a - w_b).abs().max()) < 5e-3 * float(w_b.abs().max())
