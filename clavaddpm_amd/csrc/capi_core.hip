@@ -29,7 +29,7 @@ const char* const kFamilyNames[PROF_N_FAMILIES] = {
     "gemm_f32_nn_64x64", "gemm_f32_tn_128x128", "gemm_f32_tn_64x64", "gauss_step", "multinomial_step", "logsoftmax_select_grad", "misc", "mixed_loss", "adamw_ema",
     "gmm_estep", "batchnorm_dropout", "gemm_f16x3_256x320", "gemm_f16x3_128x96", "gemm_f16x3_256x160", "gemm_f16x3_256x80", "gemm_f16x3_128x320",
     "gemm_f16x3_128x160", "gemm_f16x3_128x80", "gemm_f16x3_64x128", "gemm_f16x3_128x80_4stage", "gemm_f16x3_64x128_4stage", "gemm_f16x3_128x160_4w",
-    "gemm_f16x3_128x320_4w", "gemm_f16x3_256x160_4w", "fused_narrow"};
+    "gemm_f16x3_128x320_4w", "gemm_f16x3_256x160_4w", "fused_narrow", "gemm_f16x3_tn_128x128"};
 }  // namespace
 
 void clava_prof_begin_(int family, double flops, double bytes, hipStream_t stream) {
@@ -184,6 +184,35 @@ int clava_gemm_wgrad_f16x3(const void* dyt, long long pitch_dyt, int shift_dy, c
     g.slab_stride = slab_stride;
     if (splits == 1) { g.slabs = 1; g.kb_per_slab = 0; }
     return clava_launch_gemm_f16x3(g, tile_config, (hipStream_t)stream);
+}
+
+int clava_gemm_wgrad_f16x3_tn(const void* dy, long long pitch_dy, int shift_dy, const void* x, long long pitch_x, int shift_x,
+                              float* dw_slabs, int lddw, long long slab_stride, float* db_slabs, int M, int N_out, int K_in,
+                              int splits, void* stream) {
+    CLAVA_CHECK_ARG(M > 0 && N_out > 0 && K_in > 0 && splits >= 1 && dw_slabs, "gemm_wgrad_f16x3_tn: bad arguments");
+    CLAVA_CHECK_ARG(M % 32 == 0, "gemm_wgrad_f16x3_tn: batch %d is not a multiple of 32 (use clava_gemm_wgrad_f16x3 on transposed copies)", M);
+    CLAVA_CHECK_ARG(shift_dy + shift_x >= -60 && shift_dy + shift_x <= 60, "gemm_wgrad_f16x3_tn: shift out of range");
+    SplitGemmArgs g;
+    g.A = (const char*)dy; g.W = (const char*)x;
+    g.M = N_out; g.N = K_in; g.Kp = M; g.K = M;
+    g.pitchA = pitch_dy; g.pitchW = pitch_x;
+    g.bias = nullptr; g.bias2 = nullptr; g.act = CLAVA_ACT_NONE;
+    g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
+    g.scale_acc = ldexpf(1.f, -(shift_dy + shift_x));
+    g.alpha = 1.f; g.scale_out = 1.f;
+    g.out_split = nullptr; g.pitchOut = 0;
+    g.out_f32 = dw_slabs; g.ldc = lddw;
+    g.overflow = nullptr;
+    g.tiles_m = g.tiles_n = 0;
+    const int nkb = M >> 5;
+    g.kb_per_slab = (nkb + splits - 1) / splits;
+    g.slabs = splits;
+    CLAVA_CHECK_ARG((long long)(splits - 1) * g.kb_per_slab < nkb, "gemm_wgrad_f16x3_tn: %d splits leave empty slabs at batch %d", splits, M);
+    g.slab_stride = slab_stride;
+    g.out_colsum = db_slabs;
+    g.scale_colsum = ldexpf(1.f, -shift_dy);
+    if (splits == 1) { g.slabs = 1; g.kb_per_slab = 0; }
+    return clava_launch_gemm_f16x3_tn(g, (hipStream_t)stream);
 }
 
 int clava_gemm_f16x3_config_count_(void) { return clava_gemm_f16x3_config_count(); }

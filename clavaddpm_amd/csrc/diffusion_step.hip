@@ -84,6 +84,7 @@ __device__ __forceinline__ void multinomial_block(const MultiStepArgs& a, const 
             }
         }
         const unsigned long long pair_id = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.m + f;
+        const unsigned step_key = a.step_index + (a.step_counter ? *a.step_counter : 0u);
 
         float mx = 0.f, lsum = 0.f, lse = 0.f;
         // un-normalised log posterior of class c with logit v (REVERSE), the q_pred log-probability (QSAMPLE), or 0 (INIT)
@@ -109,7 +110,7 @@ __device__ __forceinline__ void multinomial_block(const MultiStepArgs& a, const 
         };
         auto draws = [&](int c0) {
             if (a.uniforms) return clava_rng::u4{0u, 0u, 0u, 0u};
-            return clava_rng::philox4x32_10(a.seed, pair_id, a.step_index, stream_id | ((unsigned)((c0 >> 8) * 64 + (c0 & 63)) << 3));
+            return clava_rng::philox4x32_10(a.seed, pair_id, step_key, stream_id | ((unsigned)((c0 >> 8) * 64 + (c0 & 63)) << 3));
         };
         // NW classes per lane at a time: their loads are issued together, and a block of up to NW * G classes (256 for a
         // wavefront) stays in registers through all passes
@@ -406,6 +407,16 @@ int clava_multinomial_step_f32(const clava_schedule* sched, int mode, int B, int
                                int* idx_out, const float* uniforms, int ld_u, float* x_in, int ld_xin,
                                float* log_prob, int ld_lp, const long long* t_rows, int t, unsigned long long seed,
                                unsigned long long row_offset, unsigned step_index, void* stream) {
+    return clava_multinomial_step_counter_f32(sched, mode, B, m, sumK, offsets, log_k, logits, ld_logits, idx_in, idx_out, uniforms, ld_u,
+                                              x_in, ld_xin, log_prob, ld_lp, t_rows, t, seed, row_offset, step_index, nullptr, stream);
+}
+
+int clava_multinomial_step_counter_f32(const clava_schedule* sched, int mode, int B, int m, int sumK, const int* offsets,
+                                       const float* log_k, const float* logits, int ld_logits, const int* idx_in,
+                                       int* idx_out, const float* uniforms, int ld_u, float* x_in, int ld_xin,
+                                       float* log_prob, int ld_lp, const long long* t_rows, int t, unsigned long long seed,
+                                       unsigned long long row_offset, unsigned step_index, const unsigned* step_counter,
+                                       void* stream) {
     CLAVA_CHECK_ARG(sched, "multinomial_step: null schedule");
     CLAVA_CHECK_ARG(mode >= MULTI_MODE_REVERSE && mode <= MULTI_MODE_QSAMPLE, "multinomial_step: unknown mode %d", mode);
     MultiStepArgs a;
@@ -413,7 +424,7 @@ int clava_multinomial_step_f32(const clava_schedule* sched, int mode, int B, int
     a.logits = logits; a.ld_logits = ld_logits; a.idx_in = idx_in; a.idx_out = idx_out;
     a.uniforms = uniforms; a.ld_u = ld_u; a.x_in = x_in; a.ld_xin = ld_xin; a.log_prob = log_prob; a.ld_lp = ld_lp;
     a.offsets = offsets; a.log_k = log_k; a.t_rows = t_rows; a.t = t;
-    a.seed = seed; a.row_offset = row_offset; a.step_index = step_index;
+    a.seed = seed; a.row_offset = row_offset; a.step_index = step_index; a.step_counter = step_counter;
     return clava_launch_multinomial_step(a, (hipStream_t)stream);
 }
 

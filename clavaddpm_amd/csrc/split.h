@@ -41,11 +41,18 @@ struct SplitGemmArgs {
     // blockIdx.y = slab, whose partial product goes to out_f32 + slab * slab_stride floats.  slabs <= 1: one product.
     int slabs = 1, kb_per_slab = 0;
     long long slab_stride = 0;
+    // batch-major weight-gradient kernel only: column sums of the A operand (the bias gradient sum_b dy[b][n]) go to
+    // out_colsum[slab * slab_stride + n], scaled by scale_colsum (2^-shift of dy); or null
+    float* out_colsum = nullptr;
+    float scale_colsum = 0.f;
 };
 
 // cfg < 0: pick the tile configuration for the shape; otherwise force configuration `cfg` (tools/bench_f16x3.py)
 int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream);
 int clava_gemm_f16x3_config_count();
+// weight-gradient product from batch-major operands (gemm_f16x3_tn.hip): A = dy [Kp rows = batch][M = n_out columns],
+// W = x [Kp][N = k_in], out_f32[n_out][k_in] (slabs over the batch axis as above)
+int clava_launch_gemm_f16x3_tn(SplitGemmArgs g, hipStream_t stream);
 // transposed: the packed matrix [rows, cols] is the transpose of the stored one (element (r, c) = src[c * ld + r])
 int clava_launch_split_pack(const float* src, long long ld, long long rows, int cols, int shift, char* dst,
                             long long pitch, int* overflow, hipStream_t stream, bool transposed = false);

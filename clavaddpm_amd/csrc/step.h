@@ -48,6 +48,7 @@ struct MultiStepArgs {
     const long long* t_rows; int t;
     unsigned long long seed, row_offset;
     unsigned step_index;
+    const unsigned* step_counter = nullptr;   // optional device word added to step_index (a graph replay draws afresh)
 };
 
 #ifdef __HIPCC__

@@ -4,6 +4,8 @@ Only plumbing lives here: argument checking, output allocation through torch's
 caching allocator, and the raw-pointer call.  All arithmetic is in the HIP
 library.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -156,6 +158,49 @@ def split_pack_transposed(x, shift=0, overflow=None, out=None):
     return out
 
 
+class _PackDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("ld", ctypes.c_longlong), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("scale", ctypes.c_float), ("dst", ctypes.c_void_p), ("pitch", ctypes.c_longlong), ("dst_t", ctypes.c_void_p),
+                ("pitch_t", ctypes.c_longlong)]
+
+
+class PackPlan:
+    """A fixed list of (float32 matrix, shift, SplitTensor or None, SplitTensor of the transpose or None) packed by ONE
+    launch (clava_split_pack_multi_f32).  The descriptors live in device memory and hold raw pointers: the plan is valid
+    while every tensor named keeps its storage (`key` lets the owner notice when that changed)."""
+
+    def __init__(self, items, device):
+        arr = (_PackDesc * len(items))()
+        self.keep = []
+        self.max_tiles = 1
+        for d, (src, shift, dst, dst_t) in zip(arr, items):
+            require_cuda(src)
+            if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
+                raise _lib.ClavaHipError("PackPlan: float32 row-major matrices expected")
+            rows, cols = src.shape
+            d.src, d.ld, d.rows, d.cols, d.scale = src.data_ptr(), _rs(src), rows, cols, 2.0 ** shift
+            if dst is not None:
+                if (dst.rows, dst.cols) != (rows, cols):
+                    raise _lib.ClavaHipError("PackPlan: destination has another shape")
+                dst.shift = shift
+                d.dst, d.pitch = dst.buf.data_ptr(), dst.pitch
+            if dst_t is not None:
+                if (dst_t.rows, dst_t.cols) != (cols, rows):
+                    raise _lib.ClavaHipError("PackPlan: transposed destination has another shape")
+                dst_t.shift = shift
+                d.dst_t, d.pitch_t = dst_t.buf.data_ptr(), dst_t.pitch
+            self.max_tiles = max(self.max_tiles, ((rows + 63) // 64) * ((cols + 63) // 64))
+            self.keep.append((src, dst, dst_t))
+        self.n = len(items)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.dev = raw.to(device)
+        self.key = tuple((s.data_ptr(), sh) for s, sh, _, _ in items)
+
+    def run(self, overflow=None):
+        check(lib().clava_split_pack_multi_f32(ptr(self.dev), c_int(self.n), c_int(self.max_tiles), ptr(overflow), stream_ptr()),
+              "clava_split_pack_multi_f32")
+
+
 def split_transpose(s, out=None):
     """SplitTensor of the transpose (clava_split_transpose): planes moved as they are, same shift."""
     if out is None:
@@ -182,6 +227,23 @@ def linear_wgrad_f16x3(dyt, xt, splits, out, slab_stride, tile_config=-1):
     check(lib().clava_gemm_wgrad_f16x3(ptr(dyt.buf), _lib.c_long(dyt.pitch), c_int(dyt.shift), ptr(xt.buf), _lib.c_long(xt.pitch),
                                        c_int(xt.shift), ptr(out), c_int(k_in), _lib.c_long(slab_stride), c_int(M), c_int(n_out),
                                        c_int(k_in), c_int(splits), c_int(tile_config), stream_ptr()), "clava_gemm_wgrad_f16x3")
+    return splits
+
+
+def linear_wgrad_f16x3_tn(dy, x, splits, out, slab_stride, bias_out=None):
+    """`linear_wgrad_f16x3` from the batch-major SplitTensors themselves (clava_gemm_wgrad_f16x3_tn): dy [M, N_out],
+    x [M, K_in], M a multiple of 32; no transposed copies.  `bias_out` (slabs, same stride) also receives the column sums
+    of dy (the bias gradient)."""
+    M, n_out = dy.rows, dy.cols
+    k_in = x.cols
+    if x.rows != M or M % 32:
+        raise _lib.ClavaHipError("linear_wgrad_f16x3_tn: batch mismatch or batch not a multiple of 32")
+    nkb = M // 32
+    while splits > 1 and (splits - 1) * ((nkb + splits - 1) // splits) >= nkb:
+        splits -= 1
+    check(lib().clava_gemm_wgrad_f16x3_tn(ptr(dy.buf), _lib.c_long(dy.pitch), c_int(dy.shift), ptr(x.buf), _lib.c_long(x.pitch),
+                                          c_int(x.shift), ptr(out), c_int(k_in), _lib.c_long(slab_stride), ptr(bias_out), c_int(M),
+                                          c_int(n_out), c_int(k_in), c_int(splits), stream_ptr()), "clava_gemm_wgrad_f16x3_tn")
     return splits
 
 

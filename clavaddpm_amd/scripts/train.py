@@ -131,7 +131,7 @@ class Trainer:
         # not been exercised on a multi-GPU MI355X node yet; until then data-parallel runs stay eager unless
         # CLAVA_TRAIN_GRAPH_DP=1 (the collective is outside the captured region either way)
         use_graph = self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP") == "1")
-        if (st is not None and not st.due() and draws is None and not d.has_cat and use_graph):
+        if (st is not None and not st.due() and draws is None and use_graph):
             done = self._graphed_split_step(x, st)
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
@@ -156,7 +156,8 @@ class Trainer:
         The step is ~100 small host calls; at 1.0 ms of GPU work per step the Python side is the bottleneck otherwise.
         The graph is re-captured whenever the plane scales change (every calibration) or the batch shape does; the
         first split step after a calibration runs eagerly and allocates the buffers the capture then reuses.  Not used
-        with injected draws, categorical columns (their Philox seed is a by-value kernel argument) or CLAVA_TRAIN_GRAPH=0."""
+        with injected draws or CLAVA_TRAIN_GRAPH=0.  Tables with categorical columns replay too: their Philox key takes a
+        device step word (clava_multinomial_step_counter_f32)."""
         key = (tuple(x.shape), st.generation)
         gr = getattr(self, "_graph", None)
         if gr is None or gr["key"] != key:
@@ -167,12 +168,19 @@ class Trainer:
             net = d._denoise_fn
             static_x = x.clone()
             graph = torch.cuda.CUDAGraph()
+            if d.has_cat and getattr(self, "_cat_step", None) is None:
+                self._cat_step = torch.zeros(1, device=x.device, dtype=torch.int32)
             with torch.cuda.graph(graph):
+                # t and the Gaussian noise come from torch's graph-safe generator; the categorical draws are keyed by
+                # (seed baked in at capture, device step word advanced at the end of every replay)
                 t, noise, u, seed = _tr.draw(d, static_x, None)
-                x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed)
+                x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed,
+                                                    step_counter=self._cat_step if d.has_cat else None)
                 model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
                 _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
+                if d.has_cat:
+                    self._cat_step.add_(1)
             gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise)}
         gr["x"].copy_(x)
         gr["graph"].replay()

@@ -159,6 +159,25 @@ class SplitTrainState:
             self.bufs[key] = b
         return b
 
+    def pack_weights(self, ws, wide, device):
+        """Packs the step's weights for both products in one launch (ops.PackPlan): layers 1 .. n-2 as the forward operand
+        ("w", l) and, transposed, as the input-gradient operand ("wt", l); for wide tables also proj (forward only) and the
+        head (both).  The plan is rebuilt when a weight's storage or a scale changed."""
+        n = len(ws)
+        layers = [(l, True) for l in range(1, n - 1)]
+        if wide:
+            layers = [(0, False)] + layers + [(n - 1, True)]
+        key = tuple((ws[l].data_ptr(), self.shift_w[l]) for l, _ in layers)
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or plan.key != key:
+            items = []
+            for l, both in layers:
+                w = ws[l].detach()
+                items.append((w, self.shift_w[l], self.buf(("w", l), w.shape[0], w.shape[1], device),
+                              self.buf(("wt", l), w.shape[1], w.shape[0], device) if both else None))
+            plan = self._pack_plan = ops.PackPlan(items, device)
+        plan.run(self.flag)
+
     def calibrate(self, ws, hs, gs, x_in=None, d_out=None):
         """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step;
         x_in / d_out (denoiser input, loss gradient) fix the scales of the wide end layers' operands."""
@@ -207,11 +226,10 @@ def denoiser_forward_split(net, x_in, t, st):
     # of columns they are a few MFLOP and stay on the float32 kernels
     wide = WIDE_END_LAYERS > 0 and x_in.shape[1] >= WIDE_END_LAYERS and getattr(st, "shift_x", None) is not None
     xs = None
+    st.pack_weights(ws, wide, dev)                # every weight operand of this step's forward and input-gradient products
     if wide:
         xs = ops.split_pack(x_in, st.shift_x, st.flag, out=st.buf(("x",), B, x_in.shape[1], dev))
-        w0 = ws[0].detach()
-        w0s = ops.split_pack(w0, st.shift_w[0], st.flag, out=st.buf(("w", 0), w0.shape[0], w0.shape[1], dev))
-        h = ops.linear_f16x3(xs, w0s, bs[0].detach(), out_f32=True, overflow=st.flag)
+        h = ops.linear_f16x3(xs, st.bufs[("w", 0)], bs[0].detach(), out_f32=True, overflow=st.flag)
         h.add_(emb)                               # per-row time embedding (the split kernel's row term is batch-constant)
     else:
         h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)        # proj(x) + emb (modules.py:459), float32
@@ -220,8 +238,8 @@ def denoiser_forward_split(net, x_in, t, st):
     wsp = []
     planes_only = wgrad_split_ok(B)               # float32 activation copies only feed the float32 weight-gradient kernels
     for l in range(1, n - 1):
-        w = ws[l].detach()
-        wsp.append(ops.split_pack(w, st.shift_w[l], st.flag, out=st.buf(("w", l), w.shape[0], w.shape[1], dev)))
+        w = ws[l]
+        wsp.append(st.bufs[("w", l)])
         last = l == n - 2
         if last and not wide:                     # the head reads float32: no split copy of the last hidden activation
             hf = ops.linear_f16x3(hsplit[-1], wsp[-1], bs[l].detach(), act="relu", out_f32=True, overflow=st.flag)
@@ -236,8 +254,8 @@ def denoiser_forward_split(net, x_in, t, st):
             hf = None
         hs.append(hf)
     if wide:
-        wh = ws[n - 1].detach()
-        whs = ops.split_pack(wh, st.shift_w[n - 1], st.flag, out=st.buf(("w", n - 1), wh.shape[0], wh.shape[1], dev))
+        wh = ws[n - 1]
+        whs = st.bufs[("w", n - 1)]
         # rows padded to a multiple of 4 floats: 16-byte stores in the epilogue whatever D_in is
         d_pad = (wh.shape[0] + 3) // 4 * 4
         out = torch.empty((B, d_pad), device=dev, dtype=torch.float32)[:, :wh.shape[0]]
@@ -284,9 +302,14 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         keep.append((dy, inp, dy_split, inp_split))
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            if dy_split is not None and inp_split is not None and split_wgrad:
-                # weight gradient on the f16 matrix cores: the batch is the contraction axis, so both operands are
-                # transposed (planes moved, not re-rounded); the bias gradient still sums the float32 copy
+            if dy_split is not None and inp_split is not None and split_wgrad and M % 32 == 0:
+                # weight AND bias gradient on the f16 matrix cores straight from the batch-major planes (the kernel reads
+                # its LDS tiles transposed; the column sums of dy ride along as one more MFMA against a fragment of ones)
+                wi, bi = layout.index[prefix + ".weight"], layout.index[prefix + ".bias"]
+                ops.linear_wgrad_f16x3_tn(dy_split, inp_split, splits, slabs[:, layout.offsets[wi]:], total,
+                                          bias_out=slabs[:, layout.offsets[bi]:])
+            elif dy_split is not None and inp_split is not None and split_wgrad:
+                # batch not a multiple of 32: the product of the transposed copies (their pad columns are zeros)
                 wi = layout.index[prefix + ".weight"]
                 dyt = ops.split_transpose(dy_split, out=st.buf(("T", prefix, "dy"), dy_split.cols, dy_split.rows, dev))
                 xt = ops.split_transpose(inp_split, out=st.buf(("T", prefix, "x"), inp_split.cols, inp_split.rows, dev))
@@ -302,8 +325,8 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     if wide:
         ds = ops.split_pack(d_out, st.shift_d, st.flag, out=st.buf(("d",), M, d_out.shape[1], dev))
         param_grads_async(names[n - 1], d_out, hs[n - 2], ds, hsplit[n - 2])
-        wh = ws[n - 1].detach()
-        wht = ops.split_transpose(st.bufs[("w", n - 1)], out=st.buf(("wt", n - 1), wh.shape[1], wh.shape[0], dev))
+        wh = ws[n - 1]
+        wht = st.bufs[("wt", n - 1)]
         gs, g = ops.linear_f16x3(ds, wht, act_out=hsplit[n - 2], slope=0.0, both=True, out_shift=st.shift_g[n - 2],
                                  out=st.buf(("g", n - 2), M, wh.shape[1], dev), overflow=st.flag)
     else:
@@ -312,9 +335,8 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
     for l in range(n - 2, 0, -1):
         param_grads_async(names[l], g, hs[l - 1], gs, hsplit[l - 1])
-        w = ws[l].detach()
-        # W^T for the input gradient: the planes of the forward's packed weight, transposed (coalesced both ways)
-        wt = ops.split_transpose(st.bufs[("w", l)], out=st.buf(("wt", l), w.shape[1], w.shape[0], dev))
+        w = ws[l]
+        wt = st.bufs[("wt", l)]                   # W^T for the input gradient, packed with the forward operand (pack_weights)
         if l - 1 >= 1 and split_wgrad:            # weight and bias gradients of layer l-1 read the planes: no float32 copy
             gs = ops.linear_f16x3(gs, wt, act_out=hsplit[l - 1], slope=0.0, out_shift=st.shift_g[l - 1],
                                   out=st.buf(("g", l - 1), M, w.shape[1], dev), overflow=st.flag)
@@ -360,8 +382,10 @@ def _device_sum(v, scale):
     return out
 
 
-def noised_input(diffusion, x, t, noise, uniforms, seed):
-    """q-sample both halves straight into the denoiser input buffer.  Returns (x_in, noise, idx0, idxt)."""
+def noised_input(diffusion, x, t, noise, uniforms, seed, step_counter=None):
+    """q-sample both halves straight into the denoiser input buffer.  Returns (x_in, idx0, idxt).  `step_counter` (a
+    one-element int32 device tensor, or None) is added to the categorical generator's step key on the device: a captured
+    step advances it once per replay instead of taking a new `seed` from the host."""
     dev = x.device
     B = x.shape[0]
     n = diffusion.num_numerical_features
@@ -378,11 +402,12 @@ def noised_input(diffusion, x, t, noise, uniforms, seed):
         idx0 = x[:, n:].to(torch.int32).contiguous()           # `x_cat.long()` of :650
         idxt = torch.empty_like(idx0)
         xin_cat = x_in[:, n:]
-        check(lib().clava_multinomial_step_f32(ctypes.byref(sched), c_int(2), c_int(B), c_int(m), c_int(sk),
-                                               ptr(diffusion._offsets_i32), ptr(diffusion._log_k), None, c_int(0), ptr(idx0), ptr(idxt),
-                                               ptr(uniforms), c_int(sk), ptr(xin_cat), c_int(D), None, c_int(0), ptr(t), c_int(0),
-                                               _lib.c_u64(seed), _lib.c_u64(0), ctypes.c_uint(0), stream_ptr()),
-              "clava_multinomial_step_f32(q_sample)")
+        check(lib().clava_multinomial_step_counter_f32(ctypes.byref(sched), c_int(2), c_int(B), c_int(m), c_int(sk),
+                                                       ptr(diffusion._offsets_i32), ptr(diffusion._log_k), None, c_int(0), ptr(idx0),
+                                                       ptr(idxt), ptr(uniforms), c_int(sk), ptr(xin_cat), c_int(D), None, c_int(0),
+                                                       ptr(t), c_int(0), _lib.c_u64(seed), _lib.c_u64(0), ctypes.c_uint(0),
+                                                       ptr(step_counter), stream_ptr()),
+              "clava_multinomial_step_counter_f32(q_sample)")
     return x_in, idx0, idxt
 
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 102
+#define CLAVA_HIP_VERSION 105
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
@@ -88,6 +88,23 @@ int clava_split_unpack_f32(const void* src, long long pitch, long long rows, int
 int clava_split_pack_transposed_f32(const float* src, long long ld, long long rows, int cols, int shift, void* dst,
                                     long long pitch, int* overflow, void* stream);
 
+/* One launch for a list of matrices, both orientations: descs_dev[i] (DEVICE array of n descriptors) names a float32
+ * matrix src[rows, cols] (leading dimension ld), the factor scale = 2^shift, and where its split rows go: dst
+ * [rows, cols] (pitch) and / or dst_t = the split rows of the TRANSPOSE [cols, rows] (pitch_t); either may be NULL.
+ * max_tiles >= the largest ceil(rows/64) * ceil(cols/64) of the list.  The training step re-packs every hidden weight
+ * (forward operand) and its transpose (input-gradient operand, scripts/train.py:37) after each optimizer step. */
+typedef struct {
+    const float* src;
+    long long ld;
+    int rows, cols;
+    float scale;
+    void* dst;
+    long long pitch;
+    void* dst_t;
+    long long pitch_t;
+} clava_pack_desc;
+int clava_split_pack_multi_f32(const clava_pack_desc* descs_dev, int n, int max_tiles, int* overflow, void* stream);
+
 /* y[M,N] = alpha * act'(act_out)[M,N] * act( x[M,K] . w[N,K]^T + bias[N] + rowadd[N] )
  * x, w: split rows with shifts shift_x, shift_w; y_split (shift_y) and/or y_f32 (ldy) receive the result; act_out
  * (split rows [M,N], any shift; or NULL) supplies the activation-derivative factor (1 where > 0 else `slope`) of the
@@ -111,6 +128,15 @@ int clava_split_transpose(const void* src, long long pitch_src, long long rows, 
 int clava_gemm_wgrad_f16x3(const void* dyt, long long pitch_dyt, int shift_dy, const void* xt, long long pitch_xt, int shift_x,
                            float* dw_slabs, int lddw, long long slab_stride, int M, int N_out, int K_in, int splits,
                            int tile_config, void* stream);
+
+/* The same weight-gradient slabs from the batch-major operands themselves: dy[M, N_out] (shift_dy) and x[M, K_in]
+ * (shift_x) as the forward / input-gradient kernels wrote them; no transposed copies (the kernel reads its LDS tiles
+ * transposed, ds_read_b64_tr_b16).  M must be a multiple of 32 (otherwise use clava_gemm_wgrad_f16x3).  db_slabs
+ * (optional) receives the bias-gradient slabs db_slabs[s*slab_stride + n] = partial_s( sum_b dy[b, n] ) from the same
+ * launch (clava_colsum_slabs_split otherwise). */
+int clava_gemm_wgrad_f16x3_tn(const void* dy, long long pitch_dy, int shift_dy, const void* x, long long pitch_x, int shift_x,
+                              float* dw_slabs, int lddw, long long slab_stride, float* db_slabs, int M, int N_out, int K_in,
+                              int splits, void* stream);
 
 /* ---- schedule tables ---------------------------------------------------------------------------------------
  * Device-resident tables of length T, built by the host exactly as GaussianMultinomialDiffusion.__init__ builds
@@ -160,6 +186,17 @@ int clava_multinomial_step_f32(const clava_schedule* sched, int mode, int B, int
                                int* idx_out, const float* uniforms, int ld_u, float* x_in, int ld_xin,
                                float* log_prob, int ld_lp, const long long* t_rows, int t, unsigned long long seed,
                                unsigned long long row_offset, unsigned step_index, void* stream);
+
+/* clava_multinomial_step_f32 whose generator key also takes a DEVICE word: the draws are keyed by
+ * step_index + *step_counter (step_counter may be NULL).  A training step captured as a HIP graph keeps seed and
+ * step_index as baked-in arguments and advances the word on the device, so every replay draws fresh uniforms for
+ * q_sample (:518-523) without a host-side argument update. */
+int clava_multinomial_step_counter_f32(const clava_schedule* sched, int mode, int B, int m, int sumK, const int* offsets,
+                                       const float* log_k, const float* logits, int ld_logits, const int* idx_in,
+                                       int* idx_out, const float* uniforms, int ld_u, float* x_in, int ld_xin,
+                                       float* log_prob, int ld_lp, const long long* t_rows, int t, unsigned long long seed,
+                                       unsigned long long row_offset, unsigned step_index, const unsigned* step_counter,
+                                       void* stream);
 
 /* x_t[B,n_num] = sqrt_alphas_cumprod[t] * x0 + sqrt_one_minus_alphas_cumprod[t] * noise, per-row t (int64):
  * gaussian_q_sample (:172-180), float32. */

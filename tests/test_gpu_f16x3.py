@@ -167,6 +167,34 @@ def test_weight_gradient_slabs_on_the_f16_matrix_cores(M, N, K, splits):
     assert relerr(got, f32) < 4e-6
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(4096, 1024, 512, 8), (4096, 512, 1024, 8), (4096, 1024, 1024, 1), (1024, 70, 45, 4),
+                                          (256, 130, 64, 8), (96, 16, 8, 3), (4096, 8397, 128, 8), (4096, 128, 8397, 8)])
+def test_weight_gradient_slabs_from_batch_major_operands(M, N, K, splits):
+    """clava_gemm_wgrad_f16x3_tn reads dy [M, N] and x [M, K] as they lie in memory (LDS tiles read transposed): same slabs
+    as the product of the transposed copies (identical planes, identical products; only the order of float32 additions
+    inside a k block of 32 may differ) and float64 to 2e-6; ragged tile edges, pitches beyond the row, nothing written
+    outside a slab's matrix."""
+    g = _gen(M + N + K + 1)
+    dy = torch.randn(M, N, device=DEV, generator=g) * 0.01
+    x = torch.randn(M, K, device=DEV, generator=g).clamp_min(0)
+    ref = dy.double().T @ x.double()
+    dys, xs = ops.split_pack(dy, 12), ops.split_pack(x, 4)
+    stride = N * K + 8
+    slabs = torch.full((splits, stride), float("nan"), device=DEV)
+    used = ops.linear_wgrad_f16x3_tn(dys, xs, splits, slabs, stride)
+    assert used == splits
+    got = slabs[:, :N * K].double().sum(0).view(N, K)
+    assert relerr(got, ref) < 2e-6
+    assert bool(torch.isnan(slabs[:, N * K:]).all())
+    per = (M // 32 + splits - 1) // splits * 32
+    assert relerr(slabs[0, :N * K].view(N, K), dy[:per].double().T @ x[:per].double()) < 2e-6
+    old = torch.zeros((splits, stride), device=DEV)
+    ops.linear_wgrad_f16x3(ops.split_transpose(dys), ops.split_transpose(xs), splits, old, stride)
+    assert relerr(slabs[:, :N * K], old[:, :N * K]) < 5e-7
+    with pytest.raises(_lib.ClavaHipError):
+        ops.linear_wgrad_f16x3_tn(ops.split_pack(dy[:M - 1], 12), ops.split_pack(x[:M - 1], 4), splits, slabs, stride)
+
+
 @pytest.mark.parametrize("d_in", [6, 300])
 def test_split_training_backward_with_f16_weight_gradients_matches_the_float32_backward(d_in):
     """Batch 4096 (the configs' training batch): the whole backward into the gradient slabs, hidden-block weight gradients

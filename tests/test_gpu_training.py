@@ -228,3 +228,46 @@ def test_split_overflow_reruns_the_window_on_the_float32_kernels():
     assert np.allclose(tr_a.loss_history["gloss"].to_numpy(), tr_b.loss_history["gloss"].to_numpy(), atol=2e-3)
     assert torch.isfinite(w_a).all()
     assert float((w_a - w_b).abs().max()) < 5e-3 * float(w_b.abs().max())
+
+
+def test_mixed_table_step_replays_as_a_graph_with_fresh_categorical_draws():
+    """tables with categorical columns take the captured-step path too.  The categorical generator's
+    key reads a device step word (clava_multinomial_step_counter_f32), so two replays on the SAME batch noise the
+    categories differently, the word advances once per replay, and training still lowers both losses."""
+    from clavaddpm_amd import split_nets
+    prev = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode("f16x3")
+    try:
+        torch.manual_seed(0)
+        K, n_num, B = [4, 7, 3], 3, 1024
+        net = MLPDiffusion(n_num + sum(K), 0, "none", {"d_layers": [128, 256, 128], "dropout": 0.0}).to(DEV).train()
+        d = GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=100, device=torch.device(DEV)).to(DEV).train()
+        g = torch.Generator().manual_seed(1)
+        z = torch.randn(8192, 2, generator=g)
+        cats = torch.stack([(z[:, 0] > 0).long() * 3, (z[:, 1] * 2).clamp(-3, 3).round().long() + 3, (z[:, 0] + z[:, 1] > 0).long() * 2], 1)
+        table = torch.cat([z, z[:, :1] - z[:, 1:], cats.float()], 1)
+
+        def it():
+            while True:
+                yield table[torch.randint(0, len(table), (B,), generator=g)], torch.zeros(B, dtype=torch.long)
+
+        tr = Trainer(d, it(), lr=2e-3, weight_decay=0.0, steps=240, device=torch.device(DEV))
+        tr.log_every = 40
+        tr.run_loop()
+        gr = tr._graph
+        assert gr is not None and int(tr._cat_step.item()) > 200        # nearly every step was a replay
+        hist = tr.loss_history
+        assert hist["mloss"].iloc[-1] < 0.8 * hist["mloss"].iloc[0] and hist["gloss"].iloc[-1] < 0.8 * hist["gloss"].iloc[0], hist
+        # two replays on one batch: the log-one-hot input columns (noised categories) must differ in a fair share of rows
+        x = table[:B]
+        before = int(tr._cat_step.item())
+        tr._flatten()
+        tr._run_step(x, {"y": torch.zeros(B, dtype=torch.long)})
+        a = tr._graph["keep"][2][:, n_num:].clone()
+        tr._run_step(x, {"y": torch.zeros(B, dtype=torch.long)})
+        b = tr._graph["keep"][2][:, n_num:].clone()
+        assert int(tr._cat_step.item()) == before + 2
+        changed = float((a != b).any(dim=1).float().mean())
+        assert changed > 0.2, changed
+    finally:
+        split_nets.set_gemm_mode(prev)

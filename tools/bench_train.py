@@ -7,12 +7,12 @@ from clavaddpm_amd.scripts.train import Trainer
 from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
 L = _lib.lib(); L.clava_prof_family_name.restype = ctypes.c_char_p; nf = L.clava_prof_family_count()
 dev = "cuda"
-for mode in ("f32", "f16x3"):
+for mode in os.environ.get("MODES", "f32,f16x3").split(","):
     split_nets.set_gemm_mode(mode)
     torch.manual_seed(0)
     net = MLPDiffusion(2, 0, "none", {"d_layers": [512, 1024, 1024, 1024, 1024, 512], "dropout": 0.0}).to(dev).train()
     diff = GaussianMultinomialDiffusion(np.array([0]), 2, net, num_timesteps=1000, device=torch.device(dev)).to(dev).train()
-    data = torch.randn(4096, 2); y = torch.zeros(4096, dtype=torch.long)
+    B = int(os.environ.get("B", "4096")); data = torch.randn(B, 2); y = torch.zeros(B, dtype=torch.long)
     if os.environ.get("X_CUDA") == "1": data = data.cuda()
     tr = Trainer(diff, None, lr=6e-4, weight_decay=1e-5, steps=10**9, device=torch.device(dev))
     for _ in range(5): tr._run_step(data, {"y": y})
