@@ -112,6 +112,20 @@ class Trainer:
                 self._split.flag_reduce = _par.allreduce_max_
         return self._split
 
+    # ---- data parallel: per-layer all-reduce started from the weight-gradient stream -------------
+    def _dp_layer_done(self, prefix):
+        """Called by the split backward with the weight-gradient stream current, right after layer `prefix`'s gradient
+        slabs were enqueued: sum the slabs of that layer's (weight, bias) range into the flat gradient (pre-scaled by
+        1/world) and start its all-reduce.  The input-gradient chain of the earlier layers runs meanwhile on the main
+        stream; `_optimizer_step` waits for the handles."""
+        lay = self.layout
+        wi, bi = lay.index[prefix + ".weight"], lay.index[prefix + ".bias"]
+        lo = min(lay.offsets[wi], lay.offsets[bi])
+        hi = max(lay.offsets[i] + int(np.prod(lay.shapes[i])) for i in (wi, bi))
+        hi = min((hi + 3) // 4 * 4, lay.total)
+        _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat, lo=lo, hi=hi)
+        self._dp_pending.append((lo, hi, _par.allreduce_sum_async(self.grad_flat[lo:hi])))
+
     def _anneal_lr(self, step):
         frac_done = step / self.steps
         self.lr = self.init_lr * (1 - frac_done)
@@ -148,7 +162,10 @@ class Trainer:
         else:
             model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
             loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
-            _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
+            overlap = self.dist is not None and os.environ.get("CLAVA_DP_OVERLAP", "1") != "0"
+            self._dp_pending = [] if overlap else None
+            _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st,
+                                        on_layer_done=self._dp_layer_done if overlap else None)
         return self._optimizer_step(x, loss_multi, loss_gauss)
 
     def _graphed_split_step(self, x, st):
@@ -189,7 +206,17 @@ class Trainer:
 
     def _optimizer_step(self, x, loss_multi, loss_gauss):
         self.opt_step += 1
-        if self.dist is not None:
+        pending = getattr(self, "_dp_pending", None)
+        self._dp_pending = None
+        if self.dist is not None and pending:
+            # the layers' all-reduces were started during the backward; they must cover the flat buffer exactly once
+            covered = sorted((lo, hi) for lo, hi, _ in pending)
+            assert covered[0][0] == 0 and covered[-1][1] == self.layout.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), covered
+            for _, _, h in pending:
+                if h is not None:
+                    h.wait()
+            g, S, stride = self.grad_flat, 1, self.layout.total
+        elif self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
             _par.allreduce_sum_(self.grad_flat)              # RCCL sum over ranks of the pre-scaled flat gradient
             g, S, stride = self.grad_flat, 1, self.layout.total

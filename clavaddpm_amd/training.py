@@ -266,9 +266,11 @@ def denoiser_forward_split(net, x_in, t, st):
     return out, (x_in, te, z1, a1, hs, hsplit, xs)
 
 
-def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS):
-    """`denoiser_backward` with the input-gradient products of layers n-2 .. 1 on clava_gemm_f16x3 (weight and bias
-    gradients on the float32 kernels from the float32 copies every split product also writes)."""
+def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS, on_layer_done=None):
+    """`denoiser_backward` with the input-gradient products of layers n-2 .. 1 on clava_gemm_f16x3 and the hidden blocks'
+    weight / bias gradients on the batch-major split kernel.  `on_layer_done(prefix)` (data parallel) is called with the
+    weight-gradient stream current right after a layer's gradient slabs are enqueued: the Trainer reduces them and starts
+    that layer's all-reduce there, beside the rest of the input-gradient chain."""
     x_in, te, z1, a1, hs, hsplit, xs = saved
     wide = xs is not None
     total = layout.total
@@ -320,6 +322,8 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
                                                      stream_ptr()), "clava_colsum_slabs_split")
             else:
                 param_grads(prefix, dy, inp)
+            if on_layer_done is not None:
+                on_layer_done(prefix)
 
     # head: parameter gradients and the gradient w.r.t. the last hidden pre-activation
     if wide:
@@ -365,13 +369,15 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     return None
 
 
-def reduce_slabs(slabs, scale=1.0, out=None):
-    """Flat gradient = scale * sum over slabs (fixed order)."""
+def reduce_slabs(slabs, scale=1.0, out=None, lo=0, hi=None):
+    """Flat gradient = scale * sum over slabs (fixed order); `lo:hi` restricts it to a range of the flat buffer."""
     S, total = slabs.shape
     if out is None:
         out = torch.empty(total, device=slabs.device, dtype=torch.float32)
-    check(lib().clava_slab_reduce_f32(ptr(slabs), c_int(S), c_ll(total), c_ll(total), c_float(scale), ptr(out), stream_ptr()),
-          "clava_slab_reduce_f32")
+    hi = total if hi is None else hi
+    if hi > lo:
+        check(lib().clava_slab_reduce_f32(ptr(slabs[:, lo:]), c_int(S), c_ll(total), c_ll(hi - lo), c_float(scale), ptr(out[lo:]),
+                                          stream_ptr()), "clava_slab_reduce_f32")
     return out
 
 
