@@ -154,10 +154,10 @@ int check_split_net(const clava_split_net* n, bool need_grad, const char* who) {
 
 // forward of a split stack: outs[l] (split rows, shift_out[l]) for l < n-1, last layer to float32 `last` (ld_last)
 int split_net_forward(const clava_split_net* net, const char* x, int M, const float* rowadd0, char* const* outs, float* last,
-                      int ld_last, int* overflow, hipStream_t st) {
-    const char* in = x;
-    int shift_in = net->shift_in;
-    for (int l = 0; l < net->n_layers; ++l) {
+                      int ld_last, int* overflow, hipStream_t st, int l0 = 0) {
+    const char* in = x;                           // l0 > 0: x = activation of layer l0 - 1
+    int shift_in = l0 == 0 ? net->shift_in : net->shift_out[l0 - 1];
+    for (int l = l0; l < net->n_layers; ++l) {
         const bool is_last = l == net->n_layers - 1;
         SplitGemmArgs g;
         g.A = in; g.W = (const char*)net->w[l];
@@ -629,7 +629,11 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
     const int D = d->dims[0], nd = d->n_layers;
     const int emb_w = d->dims[1];
     const int rows_per = ((B + n_groups - 1) / n_groups + 63) / 64 * 64;     // whole 64-row blocks per group
-    const bool den_fused = c->n_num > 0 && denoiser_fusable(c, d);
+    // tables with categorical columns and no guidance network: the first layer gathers m weight columns per row
+    // (cat_input.hip) and the [B, sum K] log-one-hot image is never written; CLAVA_CAT_GATHER=0 keeps the dense product
+    const bool cat_gather = c->m > 0 && !k && d->cat_wt && d->cat_bias && (c->n_num == 0 || d->num_wt) && d->dims[1] % 128 == 0 &&
+                            nd >= 2 && env_int("CLAVA_CAT_GATHER", 1) != 0;
+    const bool den_fused = !cat_gather && c->n_num > 0 && denoiser_fusable(c, d);
     const bool cls_fused = classifier_fusable(c, k);
     if (n_groups > 1) CLAVA_CHECK_HIP(hipEventRecord(pool->begin, caller), "sample_chain_f16x3: fork");
     typedef ChainGroup Group;
@@ -646,8 +650,14 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
     auto rowp = [](char* base, long long pitch, int r0) { return base ? base + pitch * r0 : nullptr; };
     for (int gi = 0; gi < ng; ++gi) {
         const Group& G = groups[gi];
-        rc = clava_launch_chain_input(x ? x + (size_t)G.r0 * c->n_num : nullptr, idx ? idx + (size_t)G.r0 * c->m : nullptr, c->offsets,
-                                      w.x_in + (size_t)G.r0 * D, G.rows, c->n_num, c->m, c->sumK, G.den);
+        if (cat_gather) {                          // numeric columns only, rows n_num floats apart
+            if (c->n_num > 0)
+                rc = clava_launch_chain_input(x + (size_t)G.r0 * c->n_num, nullptr, c->offsets, w.x_in + (size_t)G.r0 * c->n_num, G.rows,
+                                              c->n_num, 0, 0, G.den);
+        } else {
+            rc = clava_launch_chain_input(x ? x + (size_t)G.r0 * c->n_num : nullptr, idx ? idx + (size_t)G.r0 * c->m : nullptr, c->offsets,
+                                          w.x_in + (size_t)G.r0 * D, G.rows, c->n_num, c->m, c->sumK, G.den);
+        }
         if (rc) return rc;
     }
 
@@ -662,7 +672,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             float* model_out = w.model_out + (size_t)r0 * D;
             // ---- denoiser input as split rows: packed from the float32 image once; afterwards the step kernels write the
             // next input's planes themselves (pad columns keep the zeros of this first pack)
-            if (s == 0) {
+            if (s == 0 && !cat_gather) {
                 rc = clava_launch_split_pack(x_in, D, R, D, d->shift_in, x_split, split_pitch(D), overflow, G.den);
                 if (rc) return rc;
             }
@@ -688,6 +698,22 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 rc = clava_launch_den_front(fa, D, G.den);
                 if (rc) return rc;
                 rc = split_forward_range(d, 2, nd - 2, outs[1], R, outs, overflow, G.den);
+                if (rc) return rc;
+            } else if (cat_gather) {
+                CatInputArgs ca;
+                ca.xnum = w.x_in + (size_t)r0 * c->n_num; ca.ld_x = c->n_num;
+                ca.idx = idx + (size_t)r0 * c->m;
+                ca.B = R; ca.n_num = c->n_num; ca.m = c->m; ca.d1 = d->dims[1];
+                ca.offsets = c->offsets;
+                ca.num_wt = d->num_wt; ca.cat_wt = d->cat_wt; ca.cat_bias = d->cat_bias;
+                ca.emb = c->denoiser_emb + (size_t)t * emb_w;
+                ca.log_tiny = d->log_tiny; ca.act = d->act[0];
+                ca.out = outs[0]; ca.pitch_out = split_pitch(d->dims[1]);
+                ca.scale_out = ldexpf(1.f, d->shift_out[0]);
+                ca.overflow = overflow;
+                rc = clava_launch_cat_input(ca, G.den);
+                if (rc) return rc;
+                rc = split_net_forward(d, outs[0], R, nullptr, outs, model_out, D, overflow, G.den, 1);
                 if (rc) return rc;
             } else {
                 rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, D, overflow, G.den);
@@ -782,8 +808,12 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 g.grad = grad; g.ld_grad = c->n_num;
                 g.noise = c->noise ? c->noise + ((size_t)s * B + r0) * c->n_num : nullptr;
                 g.x_in = nullptr; g.ld_xin = 0;
-                g.xs.base = x_split; g.xs.pitch = split_pitch(D); g.xs.scale = ldexpf(1.f, d->shift_in); g.xs.col0 = 0;
-                g.xs.overflow = overflow;
+                if (cat_gather) {                  // the gather layer reads the float32 numeric columns themselves
+                    g.x_in = w.x_in + (size_t)r0 * c->n_num; g.ld_xin = c->n_num;
+                } else {
+                    g.xs.base = x_split; g.xs.pitch = split_pitch(D); g.xs.scale = ldexpf(1.f, d->shift_in); g.xs.col0 = 0;
+                    g.xs.overflow = overflow;
+                }
                 g.pred_xstart = nullptr;
                 g.t_rows = nullptr; g.t = t;
                 g.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
@@ -810,8 +840,10 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 q.idx_in = idx + (size_t)r0 * c->m; q.idx_out = idx + (size_t)r0 * c->m;
                 q.uniforms = c->uniforms ? c->uniforms + ((size_t)s * B + r0) * c->sumK : nullptr; q.ld_u = c->sumK;
                 q.x_in = nullptr; q.ld_xin = 0;
-                q.xs.base = x_split; q.xs.pitch = split_pitch(D); q.xs.scale = ldexpf(1.f, d->shift_in); q.xs.col0 = c->n_num;
-                q.xs.overflow = overflow;
+                if (!cat_gather) {                 // (the gather layer only needs the new indices)
+                    q.xs.base = x_split; q.xs.pitch = split_pitch(D); q.xs.scale = ldexpf(1.f, d->shift_in); q.xs.col0 = c->n_num;
+                    q.xs.overflow = overflow;
+                }
                 q.log_prob = nullptr; q.ld_lp = 0;
                 q.offsets = c->offsets; q.log_k = c->log_k;
                 q.t_rows = nullptr; q.t = t;

@@ -37,6 +37,7 @@ enum ProfFamily {
     PROF_GEMM_F16X3,                                   // first of PROF_GEMM_F16X3_CFGS families, one per tile configuration
     PROF_FUSED_NARROW = PROF_GEMM_F16X3 + 13,          // fused_narrow.hip
     PROF_GEMM_F16X3_TN,                                // gemm_f16x3_tn.hip
+    PROF_CAT_INPUT,                                    // cat_input.hip
     PROF_N_FAMILIES
 };
 enum { PROF_GEMM_F16X3_CFGS = 13 };

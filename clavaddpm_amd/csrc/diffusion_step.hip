@@ -272,10 +272,22 @@ __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) 
     // feature, not by where it runs); a wavefront work item = one 64-lane block, or 2 / 4 / 8 narrower blocks of one row
     const int n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
     const int st1 = n0, st2 = n0 + n1, st3 = n0 + n1 + n2;
-    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
-        const int bk = feature_bucket(s_off[i + 1] - s_off[i]);
-        const int pos = atomicAdd(&s_fill[bk], 1);
-        s_perm[(bk == 0 ? 0 : bk == 1 ? st1 : bk == 2 ? st2 : st3) + pos] = i;
+    // The order must be THE SAME in every workgroup: a work item is "features perm[8w .. 8w+7] of row r", and the items of
+    // a row are spread over the whole grid.  (Positions handed out by LDS atomics depend on which wavefront gets there
+    // first once m > 64: workgroups then disagreed about what item w is and some (row, feature) blocks were never drawn.)
+    // One wavefront ranks the features in index order with ballots: a stable counting sort.
+    if (threadIdx.x < 64) {
+        int base[4] = {0, st1, st2, st3};
+        for (int i0 = 0; i0 < a.m; i0 += 64) {
+            const int i = i0 + (int)threadIdx.x;
+            const int bk = (i < a.m) ? feature_bucket(s_off[i + 1] - s_off[i]) : -1;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long mask = __ballot(bk == b);
+                if (bk == b) s_perm[base[b] + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = i;
+                base[b] += __popcll(mask);
+            }
+        }
     }
     __syncthreads();
     // one loop per width (a single loop over mixed items would keep all four variants' registers live at once)

@@ -51,6 +51,24 @@ struct MultiStepArgs {
     const unsigned* step_counter = nullptr;   // optional device word added to step_index (a graph replay draws afresh)
 };
 
+// first denoiser layer from (numeric columns, category indices): cat_input.hip
+struct CatInputArgs {
+    const float* xnum; int ld_x;         // [B, n_num] float32 numeric columns of the denoiser input
+    const int* idx;                       // [B, m] current categories
+    int B, n_num, m, d1;                  // d1 = width of the layer (a multiple of 128)
+    const int* offsets;                   // device [m + 1]
+    const float* num_wt;                  // [n_num][d1]: numeric columns of the layer's weight, transposed
+    const float* cat_wt;                  // [sumK][d1]: categorical columns, transposed (one gathered row per feature)
+    const float* cat_bias;                // [d1]: b + log(1e-30) * (row sums of the categorical columns)
+    const float* emb;                     // [d1] broadcast time-embedding row or null
+    float log_tiny;                       // log(1e-30) as float32 (tab_ddpm/utils.py:131)
+    int act;
+    char* out; long long pitch_out;       // split rows [B, d1]
+    float scale_out;
+    int* overflow;
+};
+int clava_launch_cat_input(const CatInputArgs& a, hipStream_t stream);
+
 #ifdef __HIPCC__
 #include "rng.h"
 // one element of a split row (split.h): both planes, 2-byte stores

@@ -67,7 +67,11 @@ class CSplitNet(ctypes.Structure):
                 ("fs_tail", ctypes.c_void_p),
                 ("fs_back", ctypes.c_void_p),
                 ("fs_head", ctypes.c_void_p),
-                ("bf", ctypes.POINTER(ctypes.c_void_p))]
+                ("bf", ctypes.POINTER(ctypes.c_void_p)),
+                ("num_wt", ctypes.c_void_p),
+                ("cat_wt", ctypes.c_void_p),
+                ("cat_bias", ctypes.c_void_p),
+                ("log_tiny", ctypes.c_float)]
 
 
 def shift_for(maxabs, target=TARGET_LOG2):
@@ -174,7 +178,7 @@ def calibration_input(n_num, offsets, device):
 class SplitNet:
     """Packed weights, folded biases and calibrated shifts of one stack; `.c` is the clava_split_net to pass by reference."""
 
-    def __init__(self, ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False):
+    def __init__(self, ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False, cat=None):
         from .tab_ddpm.modules import run_stack
         dev = ws[0].device
         n = len(ws)
@@ -255,6 +259,19 @@ class SplitNet:
         for name in ("fs_front", "fs_tail", "fs_back", "fs_head"):
             t = getattr(self, name)
             setattr(c, name, t.data_ptr() if t is not None else None)
+        # ---- gather form of the first layer for tables with categorical columns (csrc/cat_input.hip): cat = (n_num, sum K)
+        self.num_wt = self.cat_wt = self.cat_bias = None
+        if cat is not None and not need_grad and cat[1] > 0 and d[1] % 128 == 0 and cat[0] + cat[1] == d[0]:
+            n_num = cat[0]
+            log_tiny = float(torch.log(torch.tensor(1e-30, dtype=torch.float32)))     # index_to_log_onehot's clamp (utils.py:131)
+            w0 = fw[0]
+            self.num_wt = w0[:, :n_num].t().contiguous() if n_num > 0 else None
+            self.cat_wt = w0[:, n_num:].t().contiguous()
+            self.cat_bias = (fb[0].double() + log_tiny * w0[:, n_num:].double().sum(dim=1)).float().contiguous()
+            c.num_wt = self.num_wt.data_ptr() if self.num_wt is not None else None
+            c.cat_wt = self.cat_wt.data_ptr()
+            c.cat_bias = self.cat_bias.data_ptr()
+            c.log_tiny = log_tiny
         self.c = c
 
 
@@ -300,7 +317,7 @@ def _versions(tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
 
-def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False, watch=None):
+def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_grad=False, watch=None, cat=None):
     """SplitNet for these weights, cached until a weight changes.
 
     `watch` = every tensor the prepared network depends on (the module's parameters and BatchNorm buffers, the
@@ -311,7 +328,7 @@ def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_g
     tensor by the allocator while the entry exists."""
     watch = [t.detach() for t in (watch if watch is not None else list(ws) + list(bs)) if t is not None]
     key = tuple((t.data_ptr(), tuple(t.shape)) for t in watch) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1],
-                                                                   os.environ.get("CLAVA_FUSED", "0"))
+                                                                   os.environ.get("CLAVA_FUSED", "0"), cat)
     hit = _cache.get(key)
     vers = _versions(watch)
     if hit is not None:
@@ -323,7 +340,7 @@ def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_g
             return hit["net"]
     else:
         sig = _fingerprint(watch)
-    net = SplitNet(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal, need_grad)
+    net = SplitNet(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal, need_grad, cat)
     if key not in _cache and len(_cache) >= 8:
         _cache.pop(next(iter(_cache)))
     _cache[key] = {"net": net, "sig": sig, "gen": _generation, "vers": vers, "keep": watch}

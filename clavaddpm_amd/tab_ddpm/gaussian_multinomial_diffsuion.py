@@ -266,7 +266,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         offs = self._offsets_i32.cpu().tolist() if self.has_cat else None
         x_cal, cal_max = split_nets.calibration_input(self.num_numerical_features, offs, dev)
         shift_in = split_nets.shift_for(cal_max, split_nets.IN_TARGET_LOG2)
-        den = split_nets.prepare(ws, bs, acts, None, None, den_emb, x_cal, shift_in, watch=list(self._denoise_fn.parameters()))
+        den = split_nets.prepare(ws, bs, acts, None, None, den_emb, x_cal, shift_in, watch=list(self._denoise_fn.parameters()),
+                                 cat=(self.num_numerical_features, self._sum_k) if self.has_cat else None)
         cls = None
         if guidance is not None:
             clf = guidance.classifier

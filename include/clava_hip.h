@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 105
+#define CLAVA_HIP_VERSION 106
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
@@ -311,6 +311,17 @@ typedef struct clava_split_net {
     const void* fs_back;
     const void* fs_head;
     const float* const* bf;
+    /* Optional (denoiser of a table with categorical columns; NULL: layer 0 runs as a dense product over the
+     * [B, n_num + sum K] input): layer 0 = MLPDiffusion.proj (tab_ddpm/modules.py:459) evaluated from the numeric columns
+     * and the category INDICES - the log-one-hot columns (tab_ddpm/utils.py:127-134) are 0 at the hot class and
+     * log_tiny = log(1e-30) elsewhere, so proj(x) = W_num x + cat_bias - log_tiny * sum_f W[:, n_num + off_f + idx_f].
+     * num_wt = numeric columns of w[0] transposed, float32 [n_num][dims[1]]; cat_wt = categorical columns transposed,
+     * float32 [sum K][dims[1]]; cat_bias[j] = b[0][j] + log_tiny * sum_c W[j][n_num + c] (device arrays; dims[1] a multiple
+     * of 128).  Used by clava_sample_chain_f16x3 when no classifier is given; the step kernels then write no input image. */
+    const float* num_wt;
+    const float* cat_wt;
+    const float* cat_bias;
+    float log_tiny;
 } clava_split_net;
 
 /* Same chain as clava_sample_chain_f32 (same step kernels, same noise keys) with every nn.Linear product on

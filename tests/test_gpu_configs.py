@@ -55,6 +55,32 @@ def test_scale_sweep_mixed_chain_vs_oracle(mode):
     assert relerr(x[:, :n_num], ref[:, :n_num]) < 1e-4
 
 
+@pytest.mark.parametrize("n_num,K,b,wscale", [(100, None, 4096, 0.5), (3, [4, 7, 3, 1000, 2], 1023, 0.5), (0, [5] * 70, 258, 0.05)])
+def test_gather_input_layer_matches_the_dense_product(n_num, K, b, wscale, monkeypatch):
+    """tables with categorical columns run the first layer as numeric product + m gathered weight columns
+    (csrc/cat_input.hip) and never write the [B, sum K] log-one-hot image.  Same chain with CLAVA_CAT_GATHER=0 (dense
+    K = n_num + sum K product): numeric columns to 1e-4, categories equal up to Gumbel near-ties (two correct float32-level
+    evaluations of the same layer); shapes: scale sweep, a ragged batch with a 1000-class feature, no numeric columns and
+    more than 64 features."""
+    K = _scale_sweep_K() if K is None else K
+    sumK, T = sum(K), 1000
+    net = MLPDiffusion(n_num + sumK, 0, "none", {"d_layers": [256, 512, 256], "dropout": 0.0})
+    net.load_state_dict(seeded_state(mlp_shapes(n_num + sumK, [256, 512, 256]), 17, scale=wscale))
+    d = GaussianMultinomialDiffusion(np.array(K), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    out = {}
+    n0 = split_nets.fallback_count
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CLAVA_CAT_GATHER", flag)
+        out[flag], _ = d.sample(b, torch.ones(1), seed=3, n_steps=4)
+    assert split_nets.fallback_count == n0          # both ran on the split kernels (no float16 overflow -> float32 rerun)
+    g, r = out["1"], out["0"]
+    assert torch.isfinite(g).all()
+    if n_num:
+        assert relerr(g[:, :n_num], r[:, :n_num]) < 1e-4
+    assert float((g[:, n_num:] != r[:, n_num:]).double().mean()) < 1e-4
+    assert all(int(g[:, n_num + f].max()) < K[f] and int(g[:, n_num + f].min()) >= 0 for f in range(len(K)))
+
+
 def test_scale_sweep_full_batch_both_kernel_families_agree():
     K = _scale_sweep_K()
     n_num, sumK, T, b = 100, sum(K), 1000, 4096

@@ -268,3 +268,31 @@ def test_g5_chain_with_the_reference_closure():
     ys = g["ys"]
     x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys.to(DEV)}, cond_fn=_reference_style_cond_fn(clf, 1.0), noise=sub(g, "nz:"))
     assert relerr(x, g["sample"]) < 1e-4
+
+
+@pytest.mark.parametrize("m,kf,b", [(70, 5, 258), (70, 12, 258), (70, 40, 258), (200, 3, 31), (130, 64, 17)])
+def test_categorical_draws_cover_every_feature_beyond_64_features(m, kf, b):
+    """Regression (round 2): with more than 64 features the kernel's feature ordering came out of LDS atomics issued by
+    two wavefronts, workgroups disagreed about it, and some (row, feature) blocks were never drawn (the index buffer kept
+    whatever it held).  The ordering is now a stable ballot sort.  Initial draw (:1033-1035) from injected uniforms against
+    the Gumbel arg-max of `log_sample_categorical` (:506-516) in torch, every entry written, two runs identical."""
+    import ctypes
+    from clavaddpm_amd._lib import c_int, c_u64, check, lib, ptr, stream_ptr
+    K = [kf] * m
+    sumK = sum(K)
+    net = MLPDiffusion(sumK, 0, "none", {"d_layers": [64, 64], "dropout": 0.0})
+    d = GaussianMultinomialDiffusion(np.array(K), 0, net.to(DEV).eval(), num_timesteps=50, device=torch.device(DEV)).to(DEV).eval()
+    g = torch.Generator().manual_seed(m + kf)
+    u = torch.rand(b, sumK, generator=g)
+    want = (-torch.log(-torch.log(u + 1e-30) + 1e-30)).view(b, m, kf).argmax(-1)
+    sched = d._c_schedule()
+    runs = []
+    for _ in range(2):
+        idx = torch.full((b, m), -7, device=DEV, dtype=torch.int32)
+        ud = u.to(DEV).contiguous()
+        check(lib().clava_multinomial_step_f32(ctypes.byref(sched), c_int(1), c_int(b), c_int(m), c_int(sumK), ptr(d._offsets_i32),
+                                               ptr(d._log_k), None, c_int(0), None, ptr(idx), ptr(ud), c_int(sumK), None, c_int(0), None,
+                                               c_int(0), None, c_int(0), c_u64(3), c_u64(0), ctypes.c_uint(0), stream_ptr()), "init")
+        runs.append(idx.cpu().long())
+    assert int((runs[0] == -7).sum()) == 0
+    assert torch.equal(runs[0], want) and torch.equal(runs[0], runs[1])
