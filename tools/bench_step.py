@@ -16,7 +16,7 @@ def m5_classes(m=50, lo=2, hi=1000, seed=0):
     return np.exp(rng.uniform(np.log(lo), np.log(hi), size=m)).astype(np.int64).clip(lo, hi)
 
 
-def measure(B=4096, n_num=100, K=None, T=1000, reps=20, device="cuda"):
+def measure(B=4096, n_num=100, K=None, T=1000, reps=20, device="cuda", only=None):
     from clavaddpm_amd._lib import c_int, c_u64, check, lib, ptr, stream_ptr
     from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion
     K = m5_classes() if K is None else np.asarray(K)
@@ -44,8 +44,17 @@ def measure(B=4096, n_num=100, K=None, T=1000, reps=20, device="cuda"):
                                            c_int(0), ptr(x_in[:, n_num:]), c_int(D), None, c_int(0), None, c_int(T // 2), c_u64(7),
                                            c_u64(0), ctypes.c_uint(step), stream_ptr()), "clava_multinomial_step_f32")
 
+    def multi_idx(step):      # as the chain runs it since round 2: the first layer gathers by index, no log-one-hot image is written
+        check(L.clava_multinomial_step_f32(ctypes.byref(sched), c_int(0), c_int(B), c_int(m), c_int(sk), ptr(diff._offsets_i32),
+                                           ptr(diff._log_k), ptr(model_out[:, n_num:]), c_int(D), ptr(idx), ptr(idx_out), None,
+                                           c_int(0), None, c_int(0), None, c_int(0), None, c_int(T // 2), c_u64(7),
+                                           c_u64(0), ctypes.c_uint(step), stream_ptr()), "clava_multinomial_step_f32")
+
     out = {"rows": B, "n_num": n_num, "m": m, "sum_k": sk}
-    for name, fn, nbytes in (("gauss_step", gauss, B * n_num * 28.0), ("multinomial_step", multi, B * (8.0 * sk + 8.0 * m))):
+    for name, fn, nbytes in (("gauss_step", gauss, B * n_num * 28.0), ("multinomial_step", multi, B * (8.0 * sk + 8.0 * m)),
+                             ("multinomial_step_indices_only", multi_idx, B * (4.0 * sk + 8.0 * m))):
+        if only is not None and name != only:
+            continue
         for s in range(3):
             fn(s)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -63,7 +72,7 @@ def measure(B=4096, n_num=100, K=None, T=1000, reps=20, device="cuda"):
 if __name__ == "__main__":
     import json
     if "--profile" in sys.argv:           # one shape only, for rocprofv3 runs
-        print(json.dumps(measure(B=20000, reps=10)))
+        print(json.dumps(measure(B=20000, reps=10, only=os.environ.get("STEP_ONLY"))))
         sys.exit(0)
     for B in (4096, 20000):
         print(json.dumps(measure(B=B)))
