@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 106
+#define CLAVA_HIP_VERSION 107
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
@@ -470,6 +470,16 @@ int clava_gmm_mstep_partial_f64(const double* X, long long ldx, long long N, int
                                 const double* log_prob_norm, double* workspace, double* totals, void* stream);
 int clava_gmm_mstep_finalize_f64(const double* totals, long long N, int d, int k, double reg_covar, double* weights,
                                  double* means, double* covariances, double* precisions_chol, double* stats, void* stream);
+
+/* ---- multi-parent row matching ------------------------------------------------------------------
+ * The search inside match_tables (pipeline_utils.py:1147-1205; there a faiss.IndexIVFFlat with 25 lists and nprobe 1, i.e.
+ * an APPROXIMATE search in a third-party library that is not part of the reference tree): here EXACT.  For every query row
+ * A[q, :d] the 4 nearest rows of B[nb, d] whose removed[] byte is 0 (removed may be NULL), by squared L2 distance
+ * accumulated column by column in float32, ties to the lower row index: out_idx[q*4 + k] (-1 when fewer than k+1 rows are
+ * left), out_dist[q*4 + k], ascending.  d <= 64 (-3 beyond).  workspace: clava_nn_topk_workspace_bytes(nq, nb) bytes. */
+long long clava_nn_topk_workspace_bytes(int nq, int nb);
+int clava_nn_topk_f32(const float* A, long long lda, int nq, const float* B, long long ldb, int nb, int d,
+                      const unsigned char* removed, void* workspace, int* out_idx, float* out_dist, void* stream);
 
 /* ---- k-means++ seeding on the device ------------------------------------------------------------------
  * The N-sized arithmetic of scikit-learn's `_kmeans_plusplus` (sklearn/cluster/_kmeans.py), which seeds

@@ -248,3 +248,38 @@ def test_g13_group_vote(tag):
     assert np.array_equal(assign, g["assignment"].numpy())
     assert np.array_equal(_prob_rows(prob), g["prob"].numpy())
     assert float(np.mean(agree)) == float(g["mean_agree"])
+
+
+def test_matching_oracle_follows_the_reference_statements():
+    """SURVEY 8f-4 (parity unpinned against faiss): `convert_to_unique_indices` restated against a literal transcription of
+    `pipeline_utils.py:1131-1145` semantics (smallest unused index per duplicate), and the greedy search against its
+    defining property - every query gets the nearest row not taken before it, first minimum on ties."""
+    import numpy as np
+    from oracle import matching as om
+
+    def literal(indices):
+        indices = list(indices)
+        occurrence = set()
+        candidates = set(range(len(indices))) - set(indices)
+        for i, num in enumerate(indices):
+            if num in occurrence:
+                r = min(candidates)
+                indices[i] = r
+                candidates.remove(r)
+            else:
+                occurrence.add(num)
+        return indices
+
+    rng = np.random.RandomState(3)
+    for n in (1, 7, 200):
+        raw = rng.randint(0, n, n).tolist()
+        assert om.convert_to_unique_indices(raw) == literal(raw)
+    A = rng.randint(0, 3, (40, 2)).astype(np.float32)
+    B = rng.randint(0, 3, (60, 2)).astype(np.float32)
+    idx, dist = om.match_tables(A, B, unique_matching=True)
+    free = np.ones(60, dtype=bool)
+    for i, j in enumerate(idx):
+        dd = ((B - A[i]) ** 2).sum(1)
+        dd[~free] = np.inf
+        assert j == int(np.argmin(dd)) and dist[i] == dd[j]
+        free[j] = False
