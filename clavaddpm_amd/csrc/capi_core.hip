@@ -29,7 +29,7 @@ const char* const kFamilyNames[PROF_N_FAMILIES] = {
     "gemm_f32_nn_64x64", "gemm_f32_tn_128x128", "gemm_f32_tn_64x64", "gauss_step", "multinomial_step", "logsoftmax_select_grad", "misc", "mixed_loss", "adamw_ema",
     "gmm_estep", "batchnorm_dropout", "gemm_f16x3_256x320", "gemm_f16x3_128x96", "gemm_f16x3_256x160", "gemm_f16x3_256x80", "gemm_f16x3_128x320",
     "gemm_f16x3_128x160", "gemm_f16x3_128x80", "gemm_f16x3_64x128", "gemm_f16x3_128x80_4stage", "gemm_f16x3_64x128_4stage", "gemm_f16x3_128x160_4w",
-    "gemm_f16x3_128x320_4w", "gemm_f16x3_256x160_4w", "fused_narrow", "gemm_f16x3_tn", "cat_input_layer"};
+    "gemm_f16x3_128x320_4w", "gemm_f16x3_256x160_4w", "gemm_f16x3_128x128", "gemm_f16x3_128x128_4stage", "fused_narrow", "gemm_f16x3_tn", "cat_input_layer"};
 }  // namespace
 
 void clava_prof_begin_(int family, double flops, double bytes, hipStream_t stream) {

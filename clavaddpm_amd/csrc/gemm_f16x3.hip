@@ -438,6 +438,8 @@ const TileCfg kCfgs[] = {
     CLAVA_CFG4(128, 160, 2, 2, 2),  // 10: four waves of 64 x 80, two workgroups per CU (their barriers are not in step)
     CLAVA_CFG4(128, 320, 2, 2, 1),  // 11: four waves of 64 x 160
     CLAVA_CFG4(256, 160, 2, 2, 1),  // 12: four waves of 128 x 80
+    CLAVA_CFG(128, 128, 2, 2),   // 13, 14: square tiles for M = 4096 (training): 1024-wide layers in one round of 256 tiles
+    CLAVA_CFG(128, 128, 2, 4),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static_assert(kNumCfgs == PROF_GEMM_F16X3_CFGS, "one profiling family per tile configuration (common.h, capi_core.hip)");
@@ -446,7 +448,7 @@ bool g_attr_set[64][kNumCfgs] = {};   // per device: the LDS limit is a per-devi
 // Cost model, calibrated on MI355X with tools/bench_f16x3.py: a configuration's sustained rate on a full chip (TFLOP/s
 // algorithmic, K = 1024, M = 20000), the tiles of the most loaded CU run back to back, plus a fixed launch / prologue /
 // epilogue cost.  It reproduces the measured times of the sampling (M = 20000) and training (M = 4096) shapes to ~15 %.
-const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // 0: never picked by cost
+const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // 0: never picked by cost
 static_assert(sizeof(kRateTF) / sizeof(kRateTF[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one rate per configuration");
 
 int pick_cfg(int M, int N, int Kp) {
@@ -462,11 +464,19 @@ int pick_cfg(int M, int N, int Kp) {
         const double cost = per_cu * tile_us + 5.0;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
-    // latency-bound corner: at most one tile per CU and at most four k blocks per... stage set - take the four-stage twin
-    // (it holds 1 workgroup per CU, which only costs nothing when there is no second tile to run)
-    if ((best == 6 || best == 7) && Kp <= 256) {
-        const long long tiles = (long long)((M + kCfgs[best].bm - 1) / kCfgs[best].bm) * ((N + kCfgs[best].bn - 1) / kCfgs[best].bn);
-        if (tiles <= 256) best += 2;
+    // one-round corner (training batches, narrow outputs): when a multi-stage configuration covers the whole product with
+    // at most one workgroup per CU, all of it is resident at once and the deeper pipeline wins (measured at M = 4096,
+    // tools/bench_f16x3.py: 1024 x 1024 in 26.9 us on 128 x 128 four-stage tiles against 30.3 us; N = 512 in 16.4 us on
+    // 64 x 128 four-stage tiles against 23.2 us).  Largest tile first; a configuration must fill at least 5/8 of the chip,
+    // except the smallest one, which is the fallback of this corner whenever it fits in one round.
+    const int one_round[] = {14, 9};
+    for (int c : one_round) {
+        const long long tiles = (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((N + kCfgs[c].bn - 1) / kCfgs[c].bn);
+        if (tiles <= 256 && (tiles >= 160 || c == 9) && !(kCfgs[c].bn > 64 && N <= kCfgs[c].bn / 2)) return c;
+    }
+    if (best == 6) {
+        const long long tiles = (long long)((M + kCfgs[6].bm - 1) / kCfgs[6].bm) * ((N + kCfgs[6].bn - 1) / kCfgs[6].bn);
+        if (tiles <= 256 && Kp <= 256) best = 8;
     }
     return best;
 }
