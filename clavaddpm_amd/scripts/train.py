@@ -139,16 +139,19 @@ class Trainer:
                 v = self.layout.view(self.ema_flat, name)
                 v.copy_(p.data)
                 p.data = v
-        x = x.to(self.device)
         st = self._split_state()
         # graph replay next to a process group: capture with RCCL's watchdog thread alive is supported by PyTorch, but it has
         # not been exercised on a multi-GPU MI355X node yet; until then data-parallel runs stay eager unless
         # CLAVA_TRAIN_GRAPH_DP=1 (the collective is outside the captured region either way)
         use_graph = self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP") == "1")
         if (st is not None and not st.due() and draws is None and use_graph):
+            # a host batch is copied straight into the graph's input buffer (one pageable copy, no device-to-device hop).
+            # A ring of pinned buffers with asynchronous copies was measured and is SLOWER here (1.03 vs 0.765 ms/step):
+            # the copy engine's cross-queue hand-over costs more than the 18 us the host-side wait does
             done = self._graphed_split_step(x, st)
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
+        x = x.to(self.device)
         t, noise, u, seed = _tr.draw(d, x, draws)
         x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
         if st is None or st.due():
@@ -183,13 +186,14 @@ class Trainer:
                 return None
             d = self.diffusion
             net = d._denoise_fn
-            static_x = x.clone()
+            static_x = x.to(self.device, copy=True)
             graph = torch.cuda.CUDAGraph()
             if d.has_cat and getattr(self, "_cat_step", None) is None:
-                self._cat_step = torch.zeros(1, device=x.device, dtype=torch.int32)
+                self._cat_step = torch.zeros(1, device=self.flat.device, dtype=torch.int32)
             with torch.cuda.graph(graph):
                 # t and the Gaussian noise come from torch's graph-safe generator; the categorical draws are keyed by
                 # (seed baked in at capture, device step word advanced at the end of every replay)
+                st.start_pack(net, d.num_numerical_features + d._sum_k)      # denoiser input width
                 t, noise, u, seed = _tr.draw(d, static_x, None)
                 x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed,
                                                     step_counter=self._cat_step if d.has_cat else None)
@@ -230,7 +234,9 @@ class Trainer:
                                         stream_ptr()), "clava_adamw_ema_f32")
         from .. import split_nets
         split_nets.invalidate()      # the kernel above rewrote the parameters through raw pointers: packed copies are stale
-        zero = torch.zeros((), device=x.device)
+        zero = getattr(self, "_zero", None)
+        if zero is None:
+            zero = self._zero = torch.zeros((), device=self.flat.device)
         return (loss_multi if loss_multi is not None else zero), (loss_gauss if loss_gauss is not None else zero)
 
     # ---- split-f16 overflow: snapshot at every calibration, replay of the window on the float32 kernels ---------------

@@ -22,6 +22,7 @@ from .tab_ddpm.modules import timestep_embedding
 c_ll = ctypes.c_longlong
 WGRAD_F16X3 = os.environ.get("CLAVA_WGRAD_F16X3", "1") != "0"   # hidden-block weight gradients on the split-f16 kernels
 WIDE_END_LAYERS = int(os.environ.get("CLAVA_WIDE_END_LAYERS", "256"))   # D_in from which proj / head run split-f16 too (0 = never)
+TAIL_BRANCHES = os.environ.get("CLAVA_TAIL_BRANCHES", "1") != "0"   # proj / time-embedding gradients on parallel streams
 GRAD_SPLITS = int(os.environ.get("CLAVA_GRAD_SPLITS", "8"))   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
 
@@ -147,10 +148,13 @@ class SplitTrainState:
     def due(self):
         return self.shift_h is None or self.steps_since >= self.period
 
-    def side_stream(self, device):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+    def side_stream(self, device, which=0):
+        """Stream `which` of the step's parallel branches (0: weight gradients / weight packing; 1, 2: the small
+        products at the end of the backward)."""
+        ss = self.__dict__.setdefault("_sides", {})
+        if which not in ss:
+            ss[which] = torch.cuda.Stream(device=device)
+        return ss[which]
 
     def buf(self, key, rows, cols, device):
         b = self.bufs.get(key)
@@ -177,6 +181,26 @@ class SplitTrainState:
                               self.buf(("wt", l), w.shape[1], w.shape[0], device) if both else None))
             plan = self._pack_plan = ops.PackPlan(items, device)
         plan.run(self.flag)
+
+    def wide(self, d_in):
+        """Whether proj / head of a `d_in`-column table run on the split-f16 kernels too."""
+        return WIDE_END_LAYERS > 0 and d_in >= WIDE_END_LAYERS and getattr(self, "shift_x", None) is not None
+
+    def start_pack(self, net, d_in):
+        """Starts this step's weight packing on stream 0 of the parallel branches, forked from the current stream: the
+        packing only depends on the weights, so a step calls this before it draws t and the noise and the packing runs
+        beside the whole front of the step.  `denoiser_forward_split` joins it before its first split product."""
+        ws = net.stack()[0]
+        dev = ws[0].device
+        main = torch.cuda.current_stream()
+        side = self.side_stream(dev)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            self.pack_weights(ws, self.wide(d_in), dev)   # every weight operand of this step's forward and input-gradient products
+            self._packed = torch.cuda.Event()
+            self._packed.record(side)
 
     def calibrate(self, ws, hs, gs, x_in=None, d_out=None):
         """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step;
@@ -212,22 +236,28 @@ def wgrad_split_ok(batch, splits=None):
 
 def denoiser_forward_split(net, x_in, t, st):
     """`denoiser_forward` with the hidden blocks (layers 1 .. n-2 of the stack) on clava_gemm_f16x3."""
+    ws, bs, acts = net.stack()
+    dev = x_in.device
+    wide = st.wide(x_in.shape[1])
+    # the weight packing runs on a second stream (a parallel branch of the captured graph), started by the caller before
+    # the draws or here, and is joined before the first split product
+    main = torch.cuda.current_stream()
+    if getattr(st, "_packed", None) is None:
+        st.start_pack(net, x_in.shape[1])
+    packed, st._packed = st._packed, None
     te = timestep_embedding(t, net.dim_t)
     w0, b0 = net.time_embed[0].weight.detach(), net.time_embed[0].bias.detach()
     w2, b2 = net.time_embed[2].weight.detach(), net.time_embed[2].bias.detach()
     z1 = ops.linear(te, w0, b0)
     a1 = _silu(z1)
     emb = ops.linear(a1, w2, b2)
-    ws, bs, acts = net.stack()
     n = len(ws)
-    dev = x_in.device
     B = x_in.shape[0]
     # D_in-wide end layers (one-hot heavy tables, BASELINE.json configs[4]) go to the f16 matrix cores too; at a handful
     # of columns they are a few MFLOP and stay on the float32 kernels
-    wide = WIDE_END_LAYERS > 0 and x_in.shape[1] >= WIDE_END_LAYERS and getattr(st, "shift_x", None) is not None
     xs = None
-    st.pack_weights(ws, wide, dev)                # every weight operand of this step's forward and input-gradient products
     if wide:
+        main.wait_event(packed)
         xs = ops.split_pack(x_in, st.shift_x, st.flag, out=st.buf(("x",), B, x_in.shape[1], dev))
         h = ops.linear_f16x3(xs, st.bufs[("w", 0)], bs[0].detach(), out_f32=True, overflow=st.flag)
         h.add_(emb)                               # per-row time embedding (the split kernel's row term is batch-constant)
@@ -235,6 +265,8 @@ def denoiser_forward_split(net, x_in, t, st):
         h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)        # proj(x) + emb (modules.py:459), float32
     hs = [h]
     hsplit = [ops.split_pack(h, st.shift_h[0], st.flag, out=st.buf(("h", 0), B, h.shape[1], dev))]
+    if not wide:
+        main.wait_event(packed)
     wsp = []
     planes_only = wgrad_split_ok(B)               # float32 activation copies only feed the float32 weight-gradient kernels
     for l in range(1, n - 1):
@@ -298,7 +330,7 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     # every slab must be written each step: the split product needs `splits` non-empty ranges of whole 32-row blocks
     split_wgrad = wgrad_split_ok(M, splits)
 
-    def param_grads_async(prefix, dy, inp, dy_split=None, inp_split=None):
+    def param_grads_async(prefix, dy, inp, dy_split=None, inp_split=None, side=side):
         ev = torch.cuda.Event()
         ev.record(main)
         keep.append((dy, inp, dy_split, inp_split))
@@ -353,17 +385,28 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
                                      overflow=st.flag)
         else:                                     # only the float32 gradient is needed
             g = ops.linear_f16x3(gs, wt, out_f32=True, overflow=st.flag)
+    # the end of the backward is five small products that only share g (and d_z1): three parallel branches instead of a
+    # queue behind the hidden blocks' weight gradients -- proj on stream 1, time_embed.2 on stream 2, the chain
+    # d_a1 -> d_z1 -> time_embed.0 on the main stream
+    tail = [st.side_stream(dev, 1), st.side_stream(dev, 2)] if TAIL_BRANCHES else [side, side]
     if wide:
-        param_grads_async("proj", g, x_in, gs, xs)
+        param_grads_async("proj", g, x_in, gs, xs, side=tail[0])
     else:
-        param_grads_async("proj", g, x_in)
-    param_grads_async("time_embed.2", g, a1)
+        param_grads_async("proj", g, x_in, side=tail[0])
+    param_grads_async("time_embed.2", g, a1, side=tail[1])
     d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
     d_z1 = _silu_backward(z1, d_a1)
-    param_grads_async("time_embed.0", d_z1, te)
-    done = torch.cuda.Event()
-    done.record(side)
-    main.wait_event(done)
+    if TAIL_BRANCHES:
+        keep.append((d_z1, te))
+        param_grads("time_embed.0", d_z1, te)
+        if on_layer_done is not None:
+            on_layer_done("time_embed.0")
+    else:
+        param_grads_async("time_embed.0", d_z1, te)
+    for s_ in dict.fromkeys([side] + tail):
+        done = torch.cuda.Event()
+        done.record(s_)
+        main.wait_event(done)
     st.keep = keep            # released by the next step, after the join above is on the main stream's queue
     st.steps_since += 1
     return None
