@@ -309,6 +309,30 @@ __global__ void __launch_bounds__(256) gauss_qsample_kernel(ScheduleDev s, int B
     }
 }
 
+// One training step's draws and the forward noising of the numeric columns in one launch: t ~ U{0..T-1} per row
+// (torch.randint of :590), noise ~ N(0, 1) (torch.randn_like of :647), x_t = gaussian_q_sample(x0, t, noise).  Draws are
+// keyed by (seed, step word, row / element): a captured step replays with fresh draws by advancing the device step word.
+__global__ void __launch_bounds__(256) train_draw_kernel(ScheduleDev s, int B, int n, const float* __restrict__ x0, long long ldx0,
+                                                         unsigned long long seed, unsigned step_index,
+                                                         const unsigned* __restrict__ step_counter, long long* __restrict__ t_out,
+                                                         float* __restrict__ noise, float* __restrict__ out, int ld_out) {
+    const unsigned step_key = step_index + (step_counter ? *step_counter : 0u);
+    const int per_row = n > 0 ? n : 1;
+    const long long total = (long long)B * per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / per_row), col = (int)(i - (long long)row * per_row);
+        const clava_rng::u4 rt = clava_rng::philox4x32_10(seed, (unsigned long long)row, step_key, clava_rng::STREAM_TRAIN_T);
+        const int tt = (int)(((unsigned long long)rt.x * (unsigned long long)s.T) >> 32);      // uniform on 0 .. T-1
+        if (col == 0) t_out[row] = tt;
+        if (n > 0) {
+            const clava_rng::u4 r = clava_rng::philox4x32_10(seed, (unsigned long long)i, step_key, clava_rng::STREAM_TRAIN_NOISE);
+            const float z = clava_rng::to_normal(r.x, r.y);
+            noise[i] = z;
+            out[(size_t)row * ld_out + col] = s.sqrt_alphas_cumprod[tt] * x0[(size_t)row * ldx0 + col] + s.sqrt_one_minus_alphas_cumprod[tt] * z;
+        }
+    }
+}
+
 // x_T ~ N(0, I): float32 normal draws (the reference draws torch.randn in float32, :1029) stored in the float64 state
 __global__ void __launch_bounds__(256) gauss_init_kernel(double* __restrict__ x, int B, int n, unsigned long long seed,
                                                          unsigned long long row_offset) {
@@ -448,6 +472,19 @@ int clava_gauss_qsample_f32(const clava_schedule* sched, int B, int n_num, const
     hipLaunchKernelGGL(gauss_qsample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *sched, B, n_num, x0, noise, t_rows,
                        x_t, ld_xt);
     CLAVA_CHECK_LAUNCH("clava_gauss_qsample_f32");
+    return CLAVA_OK;
+}
+
+int clava_train_draw_qsample_f32(const clava_schedule* sched, int B, int n_num, const float* x0, long long ldx0,
+                                 unsigned long long seed, unsigned step_index, const unsigned* step_counter, long long* t_rows,
+                                 float* noise, float* x_t, int ld_xt, void* stream) {
+    CLAVA_CHECK_ARG(sched && t_rows && B > 0 && n_num >= 0 && sched->T > 0, "train_draw_qsample: bad arguments");
+    CLAVA_CHECK_ARG(n_num == 0 || (x0 && noise && x_t && ldx0 >= n_num && ld_xt >= n_num), "train_draw_qsample: numeric operands missing");
+    const long long n = (long long)B * (n_num > 0 ? n_num : 1);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(train_draw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *sched, B, n_num, x0, ldx0, seed, step_index,
+                       step_counter, t_rows, noise, x_t, ld_xt);
+    CLAVA_CHECK_LAUNCH("clava_train_draw_qsample_f32");
     return CLAVA_OK;
 }
 

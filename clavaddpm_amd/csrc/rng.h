@@ -7,7 +7,8 @@
 
 namespace clava_rng {
 
-enum : uint32_t { STREAM_GAUSS = 0, STREAM_CAT = 1, STREAM_INIT_GAUSS = 2, STREAM_INIT_CAT = 3, STREAM_TRAIN = 4 };
+enum : uint32_t { STREAM_GAUSS = 0, STREAM_CAT = 1, STREAM_INIT_GAUSS = 2, STREAM_INIT_CAT = 3, STREAM_TRAIN = 4, STREAM_TRAIN_T = 5,
+                  STREAM_TRAIN_NOISE = 6 };
 
 struct u4 { uint32_t x, y, z, w; };
 

@@ -60,6 +60,11 @@ class Trainer:
                                       "pipeline_modules.py:52)")
         self.layout = _tr.FlatLayout(net)
         dev = next(net.parameters()).device
+        # training draws (t, Gaussian noise, categorical uniforms) come from the library's counter-based generator, keyed by
+        # a seed taken once from torch's CPU generator (torch.manual_seed makes a run repeatable) and a device step word
+        # advanced once per step, eager or replayed; CLAVA_TRAIN_DRAWS=torch draws t and the noise with torch instead
+        self._draw_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._step_word = torch.zeros(1, device=dev, dtype=torch.int32)
         total = self.layout.total
         # one flat buffer per role; while training, the module's parameters are views into `flat`
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -71,6 +76,8 @@ class Trainer:
             self.dist = torch.distributed
             self.world = self.dist.get_world_size()
             _par.broadcast_(self.flat, src=0)
+            # ranks hold different rows: they must not noise them with the same draws
+            self._draw_seed = (self._draw_seed + 0x9E3779B97F4A7C15 * self.dist.get_rank()) % (1 << 62)
         self.ema_model = deepcopy(net)
         self.ema_flat = self.flat.clone()
         for name, p in self.ema_model.named_parameters():
@@ -152,8 +159,12 @@ class Trainer:
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
         x = x.to(self.device)
-        t, noise, u, seed = _tr.draw(d, x, draws)
-        x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
+        if draws is None and _tr.DEVICE_DRAWS:
+            t, noise, x_in, idx0, idxt = _tr.draw_noised_input(d, x, self._draw_seed, self._step_word)
+            self._step_word.add_(1)
+        else:
+            t, noise, u, seed = _tr.draw(d, x, draws)
+            x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
         if st is None or st.due():
             # float32 step (always when CLAVA_GEMM=f32; every `period`-th step otherwise, to re-fix the plane scales)
             model_out, saved = _tr.denoiser_forward(net, x_in, t)
@@ -176,8 +187,10 @@ class Trainer:
         The step is ~100 small host calls; at 1.0 ms of GPU work per step the Python side is the bottleneck otherwise.
         The graph is re-captured whenever the plane scales change (every calibration) or the batch shape does; the
         first split step after a calibration runs eagerly and allocates the buffers the capture then reuses.  Not used
-        with injected draws or CLAVA_TRAIN_GRAPH=0.  Tables with categorical columns replay too: their Philox key takes a
-        device step word (clava_multinomial_step_counter_f32)."""
+        with injected draws or CLAVA_TRAIN_GRAPH=0.  The captured step draws t, the Gaussian noise and the categorical
+        uniforms from the library's counter-based generator, keyed by a seed baked in at capture and a device step word
+        that every replay advances (clava_train_draw_qsample_f32, clava_multinomial_step_counter_f32); eager steps draw
+        from torch's generator as the reference does.  CLAVA_TRAIN_DRAWS=torch keeps torch's generator in the graph."""
         key = (tuple(x.shape), st.generation)
         gr = getattr(self, "_graph", None)
         if gr is None or gr["key"] != key:
@@ -188,20 +201,28 @@ class Trainer:
             net = d._denoise_fn
             static_x = x.to(self.device, copy=True)
             graph = torch.cuda.CUDAGraph()
-            if d.has_cat and getattr(self, "_cat_step", None) is None:
-                self._cat_step = torch.zeros(1, device=self.flat.device, dtype=torch.int32)
             with torch.cuda.graph(graph):
-                # t and the Gaussian noise come from torch's graph-safe generator; the categorical draws are keyed by
-                # (seed baked in at capture, device step word advanced at the end of every replay)
                 st.start_pack(net, d.num_numerical_features + d._sum_k)      # denoiser input width
-                t, noise, u, seed = _tr.draw(d, static_x, None)
-                x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed,
-                                                    step_counter=self._cat_step if d.has_cat else None)
+                if _tr.DEVICE_DRAWS:
+                    # every draw of the step from the counter-based generator, keyed by (the Trainer's seed, device step word
+                    # advanced once per step): the same draws as the eager step, and torch's generator stays out of the graph
+                    t, noise, x_in, idx0, idxt = _tr.draw_noised_input(d, static_x, self._draw_seed, self._step_word)
+                else:
+                    # t and the Gaussian noise from torch's graph-safe generator; the categorical draws keyed as above
+                    t, noise, u, seed = _tr.draw(d, static_x, None)
+                    x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed,
+                                                        step_counter=self._step_word if d.has_cat else None)
+                if _tr.DEVICE_DRAWS or d.has_cat:
+                    # the step word advances beside the forward, on the packing stream (joined at the end of the backward)
+                    drawn = torch.cuda.Event()
+                    drawn.record()
+                    side = st.side_stream(self.flat.device)
+                    with torch.cuda.stream(side):
+                        side.wait_event(drawn)
+                        self._step_word.add_(1)
                 model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
                 _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
-                if d.has_cat:
-                    self._cat_step.add_(1)
             gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise)}
         gr["x"].copy_(x)
         gr["graph"].replay()
@@ -245,6 +266,7 @@ class Trainer:
         return {"step": step, "flat": self.flat.clone(), "ema": self.ema_flat.clone(), "m": self.exp_avg.clone(),
                 "v": self.exp_avg_sq.clone(), "opt_step": self.opt_step, "lr": self.lr, "sums": sums.clone(), "count": curr_count,
                 "rows": len(self.loss_history), "rng_cpu": torch.get_rng_state(), "rng_dev": torch.cuda.get_rng_state(dev),
+                "word": self._step_word.clone(),
                 "batches": []}
 
     def _restore(self, snap, sums):
@@ -255,6 +277,7 @@ class Trainer:
         self.loss_history = self.loss_history.iloc[:snap["rows"]].copy()
         torch.set_rng_state(snap["rng_cpu"])
         torch.cuda.set_rng_state(snap["rng_dev"], self.flat.device)
+        self._step_word.copy_(snap["word"])
         from .. import split_nets
         split_nets.invalidate()
         return snap["step"], snap["count"]

@@ -22,6 +22,8 @@ from .tab_ddpm.modules import timestep_embedding
 c_ll = ctypes.c_longlong
 WGRAD_F16X3 = os.environ.get("CLAVA_WGRAD_F16X3", "1") != "0"   # hidden-block weight gradients on the split-f16 kernels
 WIDE_END_LAYERS = int(os.environ.get("CLAVA_WIDE_END_LAYERS", "256"))   # D_in from which proj / head run split-f16 too (0 = never)
+FRONT_FUSED = os.environ.get("CLAVA_TRAIN_FRONT", "1") != "0"   # time MLP + proj + split pack of the training forward in one launch
+DEVICE_DRAWS = os.environ.get("CLAVA_TRAIN_DRAWS", "device") != "torch"   # captured step: t / noise from the in-kernel generator
 TAIL_BRANCHES = os.environ.get("CLAVA_TAIL_BRANCHES", "1") != "0"   # proj / time-embedding gradients on parallel streams
 GRAD_SPLITS = int(os.environ.get("CLAVA_GRAD_SPLITS", "8"))   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
@@ -245,30 +247,46 @@ def denoiser_forward_split(net, x_in, t, st):
     if getattr(st, "_packed", None) is None:
         st.start_pack(net, x_in.shape[1])
     packed, st._packed = st._packed, None
-    te = timestep_embedding(t, net.dim_t)
     w0, b0 = net.time_embed[0].weight.detach(), net.time_embed[0].bias.detach()
     w2, b2 = net.time_embed[2].weight.detach(), net.time_embed[2].bias.detach()
-    z1 = ops.linear(te, w0, b0)
-    a1 = _silu(z1)
-    emb = ops.linear(a1, w2, b2)
     n = len(ws)
     B = x_in.shape[0]
+    planes_only = wgrad_split_ok(B)               # float32 activation copies only feed the float32 weight-gradient kernels
     # D_in-wide end layers (one-hot heavy tables, BASELINE.json configs[4]) go to the f16 matrix cores too; at a handful
     # of columns they are a few MFLOP and stay on the float32 kernels
     xs = None
-    if wide:
-        main.wait_event(packed)
-        xs = ops.split_pack(x_in, st.shift_x, st.flag, out=st.buf(("x",), B, x_in.shape[1], dev))
-        h = ops.linear_f16x3(xs, st.bufs[("w", 0)], bs[0].detach(), out_f32=True, overflow=st.flag)
-        h.add_(emb)                               # per-row time embedding (the split kernel's row term is batch-constant)
+    fused_front = (FRONT_FUSED and not wide and net.dim_t == 128 and tuple(ws[0].shape) == (128, x_in.shape[1])
+                   and t.dtype == torch.int64 and x_in.stride(1) == 1)
+    if fused_front:
+        # timestep embedding, time MLP, proj and the split pack of h in one launch (csrc/train_front.hip)
+        from .tab_ddpm.modules import _freqs
+        te, z1, a1 = (torch.empty((B, 128), device=dev, dtype=torch.float32) for _ in range(3))
+        h = None if planes_only else torch.empty((B, 128), device=dev, dtype=torch.float32)
+        hsp = st.buf(("h", 0), B, 128, dev)
+        hsp.shift = st.shift_h[0]
+        check(lib().clava_train_front_f32(ptr(t.contiguous()), c_int(B), ptr(_freqs(128, dev)), c_int(128), ptr(x_in), c_ll(x_in.stride(0)),
+                                          c_int(x_in.shape[1]), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(ws[0].detach()), ptr(bs[0].detach()),
+                                          ptr(te), ptr(z1), ptr(a1), ptr(h), ptr(hsp.buf), c_ll(hsp.pitch), c_int(hsp.shift),
+                                          ptr(st.flag), stream_ptr()), "clava_train_front_f32")
+        hs = [h]
+        hsplit = [hsp]
     else:
-        h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)        # proj(x) + emb (modules.py:459), float32
-    hs = [h]
-    hsplit = [ops.split_pack(h, st.shift_h[0], st.flag, out=st.buf(("h", 0), B, h.shape[1], dev))]
+        te = timestep_embedding(t, net.dim_t)
+        z1 = ops.linear(te, w0, b0)
+        a1 = _silu(z1)
+        emb = ops.linear(a1, w2, b2)
+        if wide:
+            main.wait_event(packed)
+            xs = ops.split_pack(x_in, st.shift_x, st.flag, out=st.buf(("x",), B, x_in.shape[1], dev))
+            h = ops.linear_f16x3(xs, st.bufs[("w", 0)], bs[0].detach(), out_f32=True, overflow=st.flag)
+            h.add_(emb)                           # per-row time embedding (the split kernel's row term is batch-constant)
+        else:
+            h = ops.linear(x_in, ws[0].detach(), bs[0].detach(), rowadd=emb)    # proj(x) + emb (modules.py:459), float32
+        hs = [h]
+        hsplit = [ops.split_pack(h, st.shift_h[0], st.flag, out=st.buf(("h", 0), B, h.shape[1], dev))]
     if not wide:
         main.wait_event(packed)
     wsp = []
-    planes_only = wgrad_split_ok(B)               # float32 activation copies only feed the float32 weight-gradient kernels
     for l in range(1, n - 1):
         w = ws[l]
         wsp.append(st.bufs[("w", l)])
@@ -441,23 +459,54 @@ def noised_input(diffusion, x, t, noise, uniforms, seed, step_counter=None):
     D = n + diffusion._sum_k
     x_in = torch.empty((B, D), device=dev, dtype=torch.float32)
     sched = diffusion._c_schedule()
-    idx0 = idxt = None
     if n > 0:
         x_num = x[:, :n].float().contiguous()
         check(lib().clava_gauss_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(x_num), ptr(noise), ptr(t), ptr(x_in),
                                             c_int(D), stream_ptr()), "clava_gauss_qsample_f32")
-    if diffusion.has_cat:
-        m, sk = diffusion._m, diffusion._sum_k
-        idx0 = x[:, n:].to(torch.int32).contiguous()           # `x_cat.long()` of :650
-        idxt = torch.empty_like(idx0)
-        xin_cat = x_in[:, n:]
-        check(lib().clava_multinomial_step_counter_f32(ctypes.byref(sched), c_int(2), c_int(B), c_int(m), c_int(sk),
-                                                       ptr(diffusion._offsets_i32), ptr(diffusion._log_k), None, c_int(0), ptr(idx0),
-                                                       ptr(idxt), ptr(uniforms), c_int(sk), ptr(xin_cat), c_int(D), None, c_int(0),
-                                                       ptr(t), c_int(0), _lib.c_u64(seed), _lib.c_u64(0), ctypes.c_uint(0),
-                                                       ptr(step_counter), stream_ptr()),
-              "clava_multinomial_step_counter_f32(q_sample)")
+    idx0, idxt = _noised_categories(diffusion, x, x_in, t, uniforms, seed, step_counter)
     return x_in, idx0, idxt
+
+
+def _noised_categories(diffusion, x, x_in, t, uniforms, seed, step_counter):
+    """Categorical half of the forward noising (q_sample of :650-652) into x_in[:, n_num:]; returns (idx0, idxt)."""
+    if not diffusion.has_cat:
+        return None, None
+    B = x.shape[0]
+    n = diffusion.num_numerical_features
+    D = x_in.shape[1]
+    sched = diffusion._c_schedule()
+    m, sk = diffusion._m, diffusion._sum_k
+    idx0 = x[:, n:].to(torch.int32).contiguous()           # `x_cat.long()` of :650
+    idxt = torch.empty_like(idx0)
+    xin_cat = x_in[:, n:]
+    check(lib().clava_multinomial_step_counter_f32(ctypes.byref(sched), c_int(2), c_int(B), c_int(m), c_int(sk),
+                                                   ptr(diffusion._offsets_i32), ptr(diffusion._log_k), None, c_int(0), ptr(idx0),
+                                                   ptr(idxt), ptr(uniforms), c_int(sk), ptr(xin_cat), c_int(D), None, c_int(0),
+                                                   ptr(t), c_int(0), _lib.c_u64(seed), _lib.c_u64(0), ctypes.c_uint(0),
+                                                   ptr(step_counter), stream_ptr()),
+          "clava_multinomial_step_counter_f32(q_sample)")
+    return idx0, idxt
+
+
+def draw_noised_input(diffusion, x, seed, step_counter):
+    """`draw` + `noised_input` with the draws made on the device (clava_train_draw_qsample_f32): timesteps, Gaussian
+    noise and the numeric q-sample in one launch, keyed by (seed, *step_counter).  This is the captured step's form: it
+    keeps torch's generator (two fill kernels before every replay, two draw kernels in it) out of the graph.  Returns
+    (t, noise, x_in, idx0, idxt)."""
+    dev = x.device
+    B = x.shape[0]
+    n = diffusion.num_numerical_features
+    D = n + diffusion._sum_k
+    x_in = torch.empty((B, D), device=dev, dtype=torch.float32)
+    t = torch.empty(B, device=dev, dtype=torch.int64)
+    noise = torch.empty((B, n), device=dev, dtype=torch.float32) if n > 0 else None
+    xf = x if x.dtype == torch.float32 and x.stride(1) == 1 else x.float().contiguous()
+    sched = diffusion._c_schedule()
+    check(lib().clava_train_draw_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(xf), c_ll(xf.stride(0)), _lib.c_u64(seed),
+                                             ctypes.c_uint(0), ptr(step_counter), ptr(t), ptr(noise), ptr(x_in), c_int(D),
+                                             stream_ptr()), "clava_train_draw_qsample_f32")
+    idx0, idxt = _noised_categories(diffusion, x, x_in, t, None, seed, step_counter)
+    return t, noise, x_in, idx0, idxt
 
 
 def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 107
+#define CLAVA_HIP_VERSION 108
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
@@ -203,6 +203,15 @@ int clava_multinomial_step_counter_f32(const clava_schedule* sched, int mode, in
 int clava_gauss_qsample_f32(const clava_schedule* sched, int B, int n_num, const float* x0, const float* noise,
                             const long long* t_rows, float* x_t, int ld_xt, void* stream);
 
+/* One training step's draws and forward noising in one launch (mixed_loss, :644-655): t_rows[B] (int64) uniform on
+ * 0..T-1 (torch.randint of :590), noise[B,n_num] standard normal (torch.randn_like of :647), x_t = gaussian_q_sample of
+ * x0 (row stride ldx0).  The counter-based generator is keyed by (seed, step_index + *step_counter, row / element):
+ * a captured step replays with fresh draws when the caller advances the device word `step_counter` (may be NULL).
+ * n_num = 0 draws t only. */
+int clava_train_draw_qsample_f32(const clava_schedule* sched, int B, int n_num, const float* x0, long long ldx0,
+                                 unsigned long long seed, unsigned step_index, const unsigned* step_counter, long long* t_rows,
+                                 float* noise, float* x_t, int ld_xt, void* stream);
+
 /* x[B,n_num] (float64) <- standard normal draws, generated in float32 like torch.randn of :1029 / :990, from the
  * counter-based generator keyed by (seed, row_offset + row, column). */
 int clava_gauss_init_f64(double* x, int B, int n_num, unsigned long long seed, unsigned long long row_offset,
@@ -371,6 +380,17 @@ int clava_slab_reduce_f32(const float* slabs, int splits, long long slab_stride,
  * a = z * sigmoid(z);  dz = da * sigmoid(z) * (1 + z * (1 - sigmoid(z))). */
 int clava_silu_f32(const float* z, float* a, long long n, void* stream);
 int clava_silu_backward_f32(const float* z, const float* da, float* dz, long long n, void* stream);
+
+/* Front of MLPDiffusion.forward in training (per-row timesteps) as one launch: te = timestep_embedding(t)
+ * (tab_ddpm/modules.py:20-38, freqs = the dim_t/2 frequencies as float32), z1 = te W0^T + b0, a1 = SiLU(z1),
+ * emb = a1 W2^T + b2 (time_embed, modules.py:445-449, 452), h = x_in Wp^T + bp + emb (modules.py:459).  te, z1, a1
+ * ([B, dim_t] each) are stored for the backward; h goes to `h` (float32 [B, dim_t], may be NULL) and / or to `h_split`
+ * (split rows with `shift`, `pitch` bytes per row, may be NULL; *overflow as in clava_split_pack_f32).  dim_t must be 128
+ * (every config's value); other widths use the separate kernels. */
+int clava_train_front_f32(const long long* t, int B, const float* freqs, int dim_t, const float* x_in, long long ldx, int d_in,
+                          const float* w0, const float* b0, const float* w2, const float* b2, const float* wp, const float* bp,
+                          float* te, float* z1, float* a1, float* h, void* h_split, long long pitch, int shift, int* overflow,
+                          void* stream);
 
 /* Fused optimizer step over n contiguous parameters: gradient = grad_scale * sum_s grad_slabs[s*slab_stride + i]
  * (fixed order), then torch.optim.AdamW's update (decoupled decay, bias-corrected moments; scripts/train.py:17, 38)

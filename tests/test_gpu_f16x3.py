@@ -240,3 +240,46 @@ def test_split_training_backward_with_f16_weight_gradients_matches_the_float32_b
         # against the all-float32 backward the two chains differ where a pre-activation sits within rounding of the ReLU
         # kink: one flipped mask moves a sum of 4096 random-sign terms by ~1/64 of its size
         assert relerr(a, c) < 5e-2, name
+
+
+@pytest.mark.parametrize("B,d_in", [(4096, 2), (1003, 7), (517, 130), (16, 200)])
+def test_fused_training_front_matches_the_separate_kernels(B, d_in):
+    """csrc/train_front.hip (timestep embedding, time MLP, proj + emb, split pack of h in one launch) against the six
+    launches it replaces (tab_ddpm/modules.py:445-459).  te is bit-equal (same cosf / sinf on the same argument); the
+    products differ in summation order only: 2e-6 of the largest value, the float32 kernels' own bar.  Row counts off the
+    16-row tile and input widths off the 128-column pass are covered."""
+    from clavaddpm_amd import training as tr
+    torch.manual_seed(1)
+    net = MLPDiffusion(d_in, 0, "none", {"d_layers": [256, 256], "dropout": 0.0}).to(DEV).train()
+    g = _gen(7)
+    x_in = torch.randn(B, d_in, device=DEV, generator=g)
+    t = torch.randint(0, 1000, (B,), device=DEV, generator=g)
+    out32, saved32 = tr.denoiser_forward(net, x_in, t)
+    gs = [None] * 4
+    layout = tr.FlatLayout(net)
+    tr.denoiser_backward(net, saved32, torch.randn(B, d_in, device=DEV, generator=g) / B, layout,
+                         torch.zeros((tr.GRAD_SPLITS, layout.total), device=DEV), collect=gs)
+    st = tr.SplitTrainState()
+    st.calibrate(net.stack()[0], saved32[4], gs)
+    res = {}
+    for fused in (False, True):
+        tr.FRONT_FUSED = fused
+        try:
+            for wgrad in (True, False):                  # False: the float32 copy of h is written too
+                tr.WGRAD_F16X3 = wgrad
+                out, saved = tr.denoiser_forward_split(net, x_in, t, st)
+                torch.cuda.synchronize()
+                res[fused, wgrad] = (out, saved)
+        finally:
+            tr.FRONT_FUSED, tr.WGRAD_F16X3 = True, True
+    assert int(st.flag.item()) == 0
+    for wgrad in (True, False):
+        (out_a, sa), (out_b, sb) = res[True, wgrad], res[False, wgrad]
+        assert torch.equal(sa[1], sb[1])                                            # te
+        assert relerr(sa[2], sb[2]) < 2e-6 and relerr(sa[3], sb[3]) < 2e-6          # z1, a1
+        ha, hb = ops.split_unpack(sa[5][0]), ops.split_unpack(sb[5][0])
+        assert relerr(ha, hb) < 2e-6
+        assert relerr(ha, saved32[4][0]) < 2e-6
+        if not wgrad and B >= 32:
+            assert relerr(sa[4][0], sb[4][0]) < 2e-6                                # float32 h
+        assert relerr(out_a, out_b) < 1e-5 and relerr(out_a, out32) < 1e-5
