@@ -385,10 +385,15 @@ struct AdamArgs {
     float bc2_sqrt;    // sqrt(1 - beta2^step)
     float eps;
     float ema_rate, ema_c;
+    const float* hyper;   // device copy of the seven step-dependent / tunable scalars (clava_adamw_hyper_f32's layout), or null
 };
 
 // torch.optim.AdamW single-tensor update order: decay, lerp first moment, second moment, bias-corrected step; then the EMA
 __global__ void __launch_bounds__(256) adamw_ema_kernel(AdamArgs a) {
+    if (a.hyper) {        // a captured step: the launch arguments are frozen, the scalars come from memory
+        a.lr_wd = a.hyper[0]; a.beta1_c = a.hyper[1]; a.beta2 = a.hyper[2]; a.beta2_c = a.hyper[3];
+        a.step_size = a.hyper[4]; a.bc2_sqrt = a.hyper[5]; a.eps = a.hyper[6];
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
         float g = 0.f;
         for (int s = 0; s < a.S; ++s) g += a.g[(size_t)s * a.stride + i];
@@ -530,9 +535,39 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
     a.bc2_sqrt = (float)sqrt(bc2);
     a.eps = (float)eps;
     a.ema_rate = (float)ema_rate; a.ema_c = (float)(1.0 - ema_rate);
+    a.hyper = nullptr;
     ProfScope prof(PROF_ADAMW, 0.0, 4.0 * n * (7 + splits + (ema ? 2 : 0)), (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a);
     CLAVA_CHECK_LAUNCH("clava_adamw_ema_f32");
+    return CLAVA_OK;
+}
+
+int clava_adamw_hyper_f32(double lr, double beta1, double beta2, double eps, double weight_decay, long long step, float* hyper8) {
+    CLAVA_CHECK_ARG(hyper8 && step >= 1, "adamw_hyper: bad arguments");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hyper8[0] = (float)(lr * weight_decay);
+    hyper8[1] = (float)(1.0 - beta1);
+    hyper8[2] = (float)beta2;
+    hyper8[3] = (float)(1.0 - beta2);
+    hyper8[4] = (float)(lr / bc1);
+    hyper8[5] = (float)sqrt(bc2);
+    hyper8[6] = (float)eps;
+    hyper8[7] = 0.f;
+    return CLAVA_OK;
+}
+
+int clava_adamw_ema_hyper_f32(float* param, float* ema, float* exp_avg, float* exp_avg_sq, const float* grad_slabs, int splits,
+                              long long slab_stride, float grad_scale, long long n, const float* hyper_dev, double ema_rate,
+                              void* stream) {
+    CLAVA_CHECK_ARG(param && exp_avg && exp_avg_sq && grad_slabs && splits >= 1 && n > 0 && hyper_dev, "adamw_ema_hyper: bad arguments");
+    AdamArgs a = {};
+    a.p = param; a.ema = ema; a.m = exp_avg; a.v = exp_avg_sq; a.g = grad_slabs; a.S = splits; a.stride = slab_stride;
+    a.gscale = grad_scale; a.n = n;
+    a.ema_rate = (float)ema_rate; a.ema_c = (float)(1.0 - ema_rate);
+    a.hyper = hyper_dev;
+    ProfScope prof(PROF_ADAMW, 0.0, 4.0 * n * (7 + splits + (ema ? 2 : 0)), (hipStream_t)stream);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    CLAVA_CHECK_LAUNCH("clava_adamw_ema_hyper_f32");
     return CLAVA_OK;
 }
 

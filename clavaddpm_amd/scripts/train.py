@@ -16,6 +16,7 @@ What differs by design:
   * data parallelism (new): when torch.distributed is initialised, the flat gradient is averaged
     with one RCCL all-reduce per step; parameters are broadcast from rank 0 at construction.
 """
+import ctypes
 import os
 from copy import deepcopy
 
@@ -125,13 +126,25 @@ class Trainer:
         slabs were enqueued: sum the slabs of that layer's (weight, bias) range into the flat gradient (pre-scaled by
         1/world) and start its all-reduce.  The input-gradient chain of the earlier layers runs meanwhile on the main
         stream; `_optimizer_step` waits for the handles."""
+        lo, hi = self._layer_range(prefix)
+        _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat, lo=lo, hi=hi)
+        self._dp_pending.append((lo, hi, _par.allreduce_sum_async(self.grad_flat[lo:hi])))
+
+    def _layer_range(self, prefix):
+        """[lo, hi) of layer `prefix`'s weight and bias in the flat buffers (the layers tile it exactly)."""
         lay = self.layout
         wi, bi = lay.index[prefix + ".weight"], lay.index[prefix + ".bias"]
         lo = min(lay.offsets[wi], lay.offsets[bi])
         hi = max(lay.offsets[i] + int(np.prod(lay.shapes[i])) for i in (wi, bi))
-        hi = min((hi + 3) // 4 * 4, lay.total)
-        _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat, lo=lo, hi=hi)
-        self._dp_pending.append((lo, hi, _par.allreduce_sum_async(self.grad_flat[lo:hi])))
+        return lo, min((hi + 3) // 4 * 4, lay.total)
+
+    # ---- optimizer inside the captured step -----------------------------------------------------------------------------
+    def _adamw_range(self, lo, hi):
+        """AdamW + EMA over flat[lo:hi) from the gradient slabs, step scalars read from the device (`_hyper_dev`)."""
+        check(lib().clava_adamw_ema_hyper_f32(ptr(self.flat[lo:]), ptr(self.ema_flat[lo:]), ptr(self.exp_avg[lo:]), ptr(self.exp_avg_sq[lo:]),
+                                              ptr(self.slabs[:, lo:]), c_int(_tr.GRAD_SPLITS), c_ll(self.layout.total), c_float(1.0),
+                                              c_ll(hi - lo), ptr(self._hyper_dev), ctypes.c_double(self.ema_rate), stream_ptr()),
+              "clava_adamw_ema_hyper_f32")
 
     def _anneal_lr(self, step):
         frac_done = step / self.steps
@@ -156,6 +169,8 @@ class Trainer:
             # A ring of pinned buffers with asynchronous copies was measured and is SLOWER here (1.03 vs 0.765 ms/step):
             # the copy engine's cross-queue hand-over costs more than the 18 us the host-side wait does
             done = self._graphed_split_step(x, st)
+            if done is not None and done[2]:                  # the optimizer ran inside the graph
+                return self._loss_pair(done[0], done[1])
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
         x = x.to(self.device)
@@ -199,7 +214,15 @@ class Trainer:
                 return None
             d = self.diffusion
             net = d._denoise_fn
-            static_x = x.to(self.device, copy=True)
+            # ONE host-to-device copy per step: the batch (as float32) and the optimizer's step scalars share a buffer
+            B, Dx = x.shape
+            stage_dev = torch.zeros(B * Dx + 8, device=self.flat.device, dtype=torch.float32)
+            static_x = stage_dev[:B * Dx].view(B, Dx)
+            static_x.copy_(x)
+            self._hyper_dev = stage_dev[B * Dx:]
+            stage_host = torch.zeros(B * Dx + 8, dtype=torch.float32)
+            # optimizer inside the graph (single process only: data parallel puts an all-reduce between the two halves)
+            graph_opt = self.dist is None and os.environ.get("CLAVA_TRAIN_GRAPH_OPT", "1") != "0"
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 st.start_pack(net, d.num_numerical_features + d._sum_k)      # denoiser input width
@@ -223,11 +246,34 @@ class Trainer:
                 model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
                 _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
-            gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise)}
-        gr["x"].copy_(x)
+                if graph_opt:
+                    # ONE update over the whole flat buffer as the graph's last node.  Per-layer updates launched as soon
+                    # as a layer's gradient is complete were measured and are slower (0.78-0.82 vs 0.74 ms/step): beside
+                    # the products they slow the L2-bound matrix kernels by more than their own time, queued behind the
+                    # backward they run at 2.9 TB/s instead of 4.2
+                    self._adamw_range(0, self.layout.total)
+            gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise),
+                                "stage_dev": stage_dev, "stage_host": stage_host, "opt": graph_opt,
+                                "hyper_host": (ctypes.c_float * 8).from_address(stage_host.data_ptr() + 4 * x.numel())}
+        if gr["opt"]:
+            check(lib().clava_adamw_hyper_f32(ctypes.c_double(self.lr), ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]),
+                                              ctypes.c_double(self.eps), ctypes.c_double(self.weight_decay), c_ll(self.opt_step + 1),
+                                              gr["hyper_host"]), "clava_adamw_hyper_f32")
+            if x.is_cuda:
+                gr["x"].copy_(x)
+                gr["stage_dev"][x.numel():].copy_(gr["stage_host"][x.numel():])
+            else:
+                gr["stage_host"][:x.numel()].view(x.shape).copy_(x)
+                gr["stage_dev"].copy_(gr["stage_host"])
+        else:
+            gr["x"].copy_(x)
         gr["graph"].replay()
         st.steps_since += 1
-        return gr["lm"], gr["lg"]
+        if gr["opt"]:
+            self.opt_step += 1
+            from .. import split_nets
+            split_nets.invalidate()      # the optimizer kernels rewrote the parameters through raw pointers
+        return gr["lm"], gr["lg"], gr["opt"]
 
     def _optimizer_step(self, x, loss_multi, loss_gauss):
         self.opt_step += 1
@@ -247,7 +293,6 @@ class Trainer:
             g, S, stride = self.grad_flat, 1, self.layout.total
         else:
             g, S, stride = self.slabs, _tr.GRAD_SPLITS, self.layout.total
-        import ctypes
         check(lib().clava_adamw_ema_f32(ptr(self.flat), ptr(self.ema_flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(g), c_int(S),
                                         c_ll(stride), c_float(1.0), c_ll(self.layout.total), ctypes.c_double(self.lr),
                                         ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
@@ -255,6 +300,9 @@ class Trainer:
                                         stream_ptr()), "clava_adamw_ema_f32")
         from .. import split_nets
         split_nets.invalidate()      # the kernel above rewrote the parameters through raw pointers: packed copies are stale
+        return self._loss_pair(loss_multi, loss_gauss)
+
+    def _loss_pair(self, loss_multi, loss_gauss):
         zero = getattr(self, "_zero", None)
         if zero is None:
             zero = self._zero = torch.zeros((), device=self.flat.device)

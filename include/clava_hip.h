@@ -400,6 +400,15 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
                         long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
                         double eps, double weight_decay, long long step, double ema_rate, void* stream);
 
+/* The same update with the step-dependent scalars read from device memory, for a step captured in a hipGraph (kernel
+ * arguments are frozen at capture): clava_adamw_hyper_f32 fills hyper8[0..7] on the HOST with exactly the values
+ * clava_adamw_ema_f32 derives from (lr, betas, eps, weight_decay, step); the caller copies them to the device before each
+ * replay and passes that device pointer as hyper_dev. */
+int clava_adamw_hyper_f32(double lr, double beta1, double beta2, double eps, double weight_decay, long long step, float* hyper8);
+int clava_adamw_ema_hyper_f32(float* param, float* ema, float* exp_avg, float* exp_avg_sq, const float* grad_slabs, int splits,
+                              long long slab_stride, float grad_scale, long long n, const float* hyper_dev, double ema_rate,
+                              void* stream);
+
 /* ---- guidance-classifier training (train_classifier / numerical_forward_backward_log) --------
  * One hidden block of Classifier (pipeline_utils.py:607-617) in train mode is Linear -> ReLU/LeakyReLU -> BatchNorm1d
  * -> Dropout.  The Linear + activation is clava_gemm_bias_act_f32; these entry points are the rest.

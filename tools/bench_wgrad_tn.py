@@ -19,7 +19,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 for (N, K) in [(1024, 1024), (1024, 512), (512, 1024), (512, 128), (128, 8397)]:
     dy = ops.split_pack(torch.randn(M, N, device="cuda", generator=g) * 0.01, 12)
     x = ops.split_pack(torch.randn(M, K, device="cuda", generator=g), 4)
-    S = 8
+    S = int(os.environ.get("S", "8"))
     slabs = torch.zeros((S, N * K), device="cuda")
     dyt, xt = ops.split_transpose(dy), ops.split_transpose(x)
     t_tn = timeit(lambda: ops.linear_wgrad_f16x3_tn(dy, x, S, slabs, N * K))
