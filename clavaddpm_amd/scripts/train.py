@@ -244,7 +244,9 @@ class Trainer:
                         side.wait_event(drawn)
                         self._step_word.add_(1)
                 model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
-                lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+                # the loss means are summed on a stream the backward joins at its end: nothing in the step waits for them
+                lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t,
+                                                  aux_stream=st.side_stream(self.flat.device, 1) if _tr.TAIL_BRANCHES else None)
                 _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
                 if graph_opt:
                     # ONE update over the whole flat buffer as the graph's last node.  Per-layer updates launched as soon

@@ -24,6 +24,7 @@ WGRAD_F16X3 = os.environ.get("CLAVA_WGRAD_F16X3", "1") != "0"   # hidden-block w
 WIDE_END_LAYERS = int(os.environ.get("CLAVA_WIDE_END_LAYERS", "256"))   # D_in from which proj / head run split-f16 too (0 = never)
 FRONT_FUSED = os.environ.get("CLAVA_TRAIN_FRONT", "1") != "0"   # time MLP + proj + split pack of the training forward in one launch
 DEVICE_DRAWS = os.environ.get("CLAVA_TRAIN_DRAWS", "device") != "torch"   # captured step: t / noise from the in-kernel generator
+NARROW_ENDS = os.environ.get("CLAVA_TRAIN_NARROW", "1") != "0"   # head / proj of tables with <= 16 columns on the memory-bound kernels
 TAIL_BRANCHES = os.environ.get("CLAVA_TAIL_BRANCHES", "1") != "0"   # proj / time-embedding gradients on parallel streams
 GRAD_SPLITS = int(os.environ.get("CLAVA_GRAD_SPLITS", "8"))   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
@@ -122,6 +123,49 @@ def denoiser_backward(net, saved, d_out, layout, slabs, splits=GRAD_SPLITS, want
     if want_dx:
         return ops.linear_dgrad(g, ws[0].detach())
     return None
+
+
+def narrow_ok(w, inp_cols_first):
+    """Whether an end layer with weight `w` ([out, in]) runs on csrc/narrow.hip: its narrow side (out for the head, in
+    for proj) has at most 16 columns and the wide side meets the kernels' alignment."""
+    out_f, in_f = w.shape
+    if not NARROW_ENDS:
+        return False
+    if inp_cols_first:            # proj: narrow input
+        return in_f <= 16
+    return out_f <= 16 and in_f % 4 == 0 and out_f * in_f <= 16384
+
+
+def narrow_head(h, w, b):
+    """h [B, K] @ w[D, K]^T + b on clava_narrow_head_f32."""
+    B, K = h.shape
+    D = w.shape[0]
+    out = torch.empty((B, D), device=h.device, dtype=torch.float32)
+    check(lib().clava_narrow_head_f32(ptr(h), c_ll(h.stride(0)), c_int(B), c_int(K), ptr(w), ptr(b), c_int(D), ptr(out), c_int(D),
+                                      stream_ptr()), "clava_narrow_head_f32")
+    return out
+
+
+def narrow_dgrad(dy, w, act, slope, want_f32, out_split, shift, flag):
+    """(dy [B, D] @ w [D, J]) * act'(act) as split rows (`out_split`, may be None) and / or float32."""
+    B, D = dy.shape
+    J = w.shape[1]
+    g = torch.empty((B, J), device=dy.device, dtype=torch.float32) if want_f32 else None
+    if out_split is not None:
+        out_split.shift = shift
+    check(lib().clava_narrow_dgrad_f32(ptr(dy), c_int(dy.stride(0)), c_int(B), c_int(D), ptr(w), c_int(J), ptr(act),
+                                       c_ll(act.stride(0) if act is not None else 0), c_float(slope), ptr(g), c_ll(J),
+                                       ptr(out_split.buf) if out_split is not None else None,
+                                       c_ll(out_split.pitch if out_split is not None else 0), c_int(shift), ptr(flag), stream_ptr()),
+          "clava_narrow_dgrad_f32")
+    return g
+
+
+def narrow_wgrad(A, Bm, splits, dw, stride_d, stride_j, db_narrow, db_wide, slab_stride):
+    B, D = A.shape
+    check(lib().clava_narrow_wgrad_f32(ptr(A), c_ll(A.stride(0)), c_int(D), ptr(Bm), c_ll(Bm.stride(0)), c_int(Bm.shape[1]), c_int(B),
+                                       c_int(splits), ptr(dw), c_ll(stride_d), c_ll(stride_j), ptr(db_narrow), ptr(db_wide),
+                                       c_ll(slab_stride), stream_ptr()), "clava_narrow_wgrad_f32")
 
 
 # ------------------------------------------------------------------------- split-f16 forward / input gradients
@@ -310,6 +354,8 @@ def denoiser_forward_split(net, x_in, t, st):
         d_pad = (wh.shape[0] + 3) // 4 * 4
         out = torch.empty((B, d_pad), device=dev, dtype=torch.float32)[:, :wh.shape[0]]
         ops.linear_f16x3(hsplit[-1], whs, bs[n - 1].detach(), out_f32=True, overflow=st.flag, out=out)
+    elif narrow_ok(ws[n - 1], False) and hs[-1].stride(1) == 1 and hs[-1].stride(0) % 4 == 0:
+        out = narrow_head(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
     else:
         out = ops.linear(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
     hs.append(out)
@@ -348,13 +394,21 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     # every slab must be written each step: the split product needs `splits` non-empty ranges of whole 32-row blocks
     split_wgrad = wgrad_split_ok(M, splits)
 
-    def param_grads_async(prefix, dy, inp, dy_split=None, inp_split=None, side=side):
+    def param_grads_async(prefix, dy, inp, dy_split=None, inp_split=None, side=side, narrow=None):
         ev = torch.cuda.Event()
         ev.record(main)
         keep.append((dy, inp, dy_split, inp_split))
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            if dy_split is not None and inp_split is not None and split_wgrad and M % 32 == 0:
+            if narrow is not None:
+                # an end layer with a handful of columns on one side: weight and bias slabs from one memory-bound launch
+                wi, bi = layout.index[prefix + ".weight"], layout.index[prefix + ".bias"]
+                wsl, bsl = slabs[:, layout.offsets[wi]:], slabs[:, layout.offsets[bi]:]
+                if narrow == "head":        # dW[d][j] = sum_b dy[b][d] inp[b][j];  db = column sums of dy (the narrow side)
+                    narrow_wgrad(dy, inp, splits, wsl, inp.shape[1], 1, bsl, None, total)
+                else:                       # proj: dW[c][k] = sum_b dy[b][c] inp[b][k];  db = column sums of dy (the wide side)
+                    narrow_wgrad(inp, dy, splits, wsl, 1, inp.shape[1], None, bsl, total)
+            elif dy_split is not None and inp_split is not None and split_wgrad and M % 32 == 0:
                 # weight AND bias gradient on the f16 matrix cores straight from the batch-major planes (the kernel reads
                 # its LDS tiles transposed; the column sums of dy ride along as one more MFMA against a fragment of ones)
                 wi, bi = layout.index[prefix + ".weight"], layout.index[prefix + ".bias"]
@@ -383,6 +437,11 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         wht = st.bufs[("wt", n - 1)]
         gs, g = ops.linear_f16x3(ds, wht, act_out=hsplit[n - 2], slope=0.0, both=True, out_shift=st.shift_g[n - 2],
                                  out=st.buf(("g", n - 2), M, wh.shape[1], dev), overflow=st.flag)
+    elif narrow_ok(ws[n - 1], False):
+        param_grads_async(names[n - 1], d_out, hs[n - 2], narrow="head")
+        gs = st.buf(("g", n - 2), M, ws[n - 1].shape[1], dev)
+        # the float32 copy only feeds the float32 weight-gradient kernels of layer n-2
+        g = narrow_dgrad(d_out, ws[n - 1].detach(), hs[n - 2], 0.0, not (split_wgrad and n - 2 >= 1), gs, st.shift_g[n - 2], st.flag)
     else:
         param_grads_async(names[n - 1], d_out, hs[n - 2])
         g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
@@ -410,7 +469,7 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     if wide:
         param_grads_async("proj", g, x_in, gs, xs, side=tail[0])
     else:
-        param_grads_async("proj", g, x_in, side=tail[0])
+        param_grads_async("proj", g, x_in, side=tail[0], narrow="proj" if narrow_ok(ws[0], True) else None)
     param_grads_async("time_embed.2", g, a1, side=tail[1])
     d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
     d_z1 = _silu_backward(z1, d_a1)
@@ -443,9 +502,16 @@ def reduce_slabs(slabs, scale=1.0, out=None, lo=0, hi=None):
 
 
 # ---------------------------------------------------------------------------------------------------- losses
-def _device_sum(v, scale):
+def _device_sum(v, scale, aux_stream=None):
     out = torch.empty((), device=v.device, dtype=torch.float32)
-    check(lib().clava_sum_f32(ptr(v), c_ll(v.numel()), c_float(scale), ptr(out), stream_ptr()), "clava_sum_f32")
+    if aux_stream is None:
+        check(lib().clava_sum_f32(ptr(v), c_ll(v.numel()), c_float(scale), ptr(out), stream_ptr()), "clava_sum_f32")
+        return out
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(aux_stream):
+        aux_stream.wait_event(ev)
+        check(lib().clava_sum_f32(ptr(v), c_ll(v.numel()), c_float(scale), ptr(out), stream_ptr()), "clava_sum_f32")
     return out
 
 
@@ -509,8 +575,10 @@ def draw_noised_input(diffusion, x, seed, step_counter):
     return t, noise, x_in, idx0, idxt
 
 
-def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
-    """Both loss means (0-dim device tensors, or None for an absent half) and d(loss_multi + loss_gauss)/d(model_out)."""
+def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t, aux_stream=None):
+    """Both loss means (0-dim device tensors, or None for an absent half) and d(loss_multi + loss_gauss)/d(model_out).
+    `aux_stream`: the reductions to the two means (nothing in the step waits for them) run there, behind an event; the
+    caller joins that stream before the results are read (the captured step: a stream the backward joins at its end)."""
     B, D = model_out.shape
     n = diffusion.num_numerical_features
     dev = model_out.device
@@ -524,7 +592,7 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
         rows = torch.empty(B, device=dev, dtype=torch.float32)
         check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(ld_out), ptr(noise), ptr(rows), ptr(d_out), c_int(d_out.stride(0)),
                                              stream_ptr()), "clava_gauss_mse_loss_f32")
-        loss_gauss = _device_sum(rows, 1.0 / B)
+        loss_gauss = _device_sum(rows, 1.0 / B, aux_stream)
     if diffusion.has_cat:
         if diffusion.multinomial_loss_type != "vb_stochastic" or diffusion.parametrization != "x0":
             raise NotImplementedError("only multinomial_loss_type='vb_stochastic' with parametrization='x0' is implemented")
@@ -536,7 +604,7 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t):
                                                ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(ld_out), ptr(idx0), ptr(idxt), ptr(t),
                                                c_float(float(pt)), ptr(terms), ptr(d_out[:, n:]), c_int(d_out.stride(0)), stream_ptr()),
               "clava_multinomial_loss_f32")
-        loss_multi = _device_sum(terms, 1.0 / (m * B))
+        loss_multi = _device_sum(terms, 1.0 / (m * B), aux_stream)
     return loss_multi, loss_gauss, d_out
 
 

@@ -400,6 +400,28 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
                         long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
                         double eps, double weight_decay, long long step, double ema_rate, void* stream);
 
+/* ---- narrow end layers of the denoiser in training (csrc/narrow.hip): D <= 16 columns on one side -----------------
+ * Memory-bound replacements of the tiled products for the head Linear(K, D) and proj Linear(D, J) of numeric tables.
+ * clava_narrow_head_f32: out[b][d] = bias[d] + sum_k h[b][k] W[d][k] (tab_ddpm/modules.py:460); K % 4 == 0, rows of h
+ *   16-byte aligned, D * K <= 16384.
+ * clava_narrow_dgrad_f32: g[b][j] = act'(act[b][j]) * sum_d dy[b][d] W[d][j] (W is [D][J]; act may be NULL = no mask,
+ *   else 1 where act > 0 and `slope` elsewhere), written as float32 (g_f32, may be NULL) and / or as split rows
+ *   (g_split with shift / pitch as clava_split_pack_f32, pad columns zero, may be NULL): the input gradient of the head
+ *   with the last block's ReLU' and the split pack folded in (backward of modules.py:460, :174-180).
+ * clava_narrow_wgrad_f32: per batch range s (rows split as clava_colsum_slabs_f32 splits them),
+ *   dw_slabs[s*slab_stride + d*stride_d + j*stride_j] = sum_b A[b][d] Bm[b][j]   (A [B, D] narrow, Bm [B, J]);
+ *   db_narrow_slabs[s*slab_stride + d] = sum_b A[b][d], db_wide_slabs[s*slab_stride + j] = sum_b Bm[b][j] (either may
+ *   be NULL).  Head: A = dy, Bm = h, strides (K, 1), bias = narrow sums.  proj: A = x, Bm = g, strides (1, D), bias =
+ *   wide sums (weight half of loss.backward(), scripts/train.py:37). */
+int clava_narrow_head_f32(const float* h, long long ldh, int B, int K, const float* W, const float* bias, int D, float* out, int ld_out,
+                          void* stream);
+int clava_narrow_dgrad_f32(const float* dy, int ld_dy, int B, int D, const float* W, int J, const float* act, long long ld_act,
+                           float slope, float* g_f32, long long ldg, void* g_split, long long pitch, int shift, int* overflow,
+                           void* stream);
+int clava_narrow_wgrad_f32(const float* A, long long lda, int D, const float* Bm, long long ldb, int J, int B, int splits,
+                           float* dw_slabs, long long stride_d, long long stride_j, float* db_narrow_slabs, float* db_wide_slabs,
+                           long long slab_stride, void* stream);
+
 /* The same update with the step-dependent scalars read from device memory, for a step captured in a hipGraph (kernel
  * arguments are frozen at capture): clava_adamw_hyper_f32 fills hyper8[0..7] on the HOST with exactly the values
  * clava_adamw_ema_f32 derives from (lr, betas, eps, weight_decay, step); the caller copies them to the device before each
