@@ -411,6 +411,14 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(AdamArgs a) {
     }
 }
 
+// dst[0..n) = (word & 1 ? p1 : p0)[0..n): the captured step's input fetch.  p0 / p1 are PINNED HOST buffers the host fills
+// alternately (step parity), read here straight over the bus: no host-synchronous copy sits between two replays.
+__global__ void __launch_bounds__(256) stage_fetch_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                          const unsigned* __restrict__ word, float* __restrict__ dst, long long n) {
+    const float* src = (*word & 1u) ? p1 : p0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 inline int grid_for(long long n, int cap = 4096) {
     const long long b = (n + 255) / 256;
     return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -539,6 +547,13 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
     ProfScope prof(PROF_ADAMW, 0.0, 4.0 * n * (7 + splits + (ema ? 2 : 0)), (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a);
     CLAVA_CHECK_LAUNCH("clava_adamw_ema_f32");
+    return CLAVA_OK;
+}
+
+int clava_stage_fetch_f32(const float* host0, const float* host1, const unsigned* word, float* dst, long long n, void* stream) {
+    CLAVA_CHECK_ARG(host0 && host1 && word && dst && n > 0, "stage_fetch: bad arguments");
+    hipLaunchKernelGGL(stage_fetch_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, host0, host1, word, dst, n);
+    CLAVA_CHECK_LAUNCH("clava_stage_fetch_f32");
     return CLAVA_OK;
 }
 

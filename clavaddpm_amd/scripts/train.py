@@ -66,6 +66,7 @@ class Trainer:
         # advanced once per step, eager or replayed; CLAVA_TRAIN_DRAWS=torch draws t and the noise with torch instead
         self._draw_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self._step_word = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._host_word = 0          # host mirror of the step word (its parity picks the captured step's pinned input buffer)
         total = self.layout.total
         # one flat buffer per role; while training, the module's parameters are views into `flat`
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -174,9 +175,13 @@ class Trainer:
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
         x = x.to(self.device)
+        if st is not None and st.due() and getattr(self, "_graph", None) is not None:
+            # a calibration step synchronises anyway: check the host's mirror of the step word against the device
+            assert int(self._step_word.item()) == self._host_word, (int(self._step_word.item()), self._host_word)
         if draws is None and _tr.DEVICE_DRAWS:
             t, noise, x_in, idx0, idxt = _tr.draw_noised_input(d, x, self._draw_seed, self._step_word)
             self._step_word.add_(1)
+            self._host_word += 1
         else:
             t, noise, u, seed = _tr.draw(d, x, draws)
             x_in, idx0, idxt = _tr.noised_input(d, x, t, noise, u, seed)
@@ -206,7 +211,7 @@ class Trainer:
         uniforms from the library's counter-based generator, keyed by a seed baked in at capture and a device step word
         that every replay advances (clava_train_draw_qsample_f32, clava_multinomial_step_counter_f32); eager steps draw
         from torch's generator as the reference does.  CLAVA_TRAIN_DRAWS=torch keeps torch's generator in the graph."""
-        key = (tuple(x.shape), st.generation)
+        key = (tuple(x.shape), st.generation, x.is_cuda)
         gr = getattr(self, "_graph", None)
         if gr is None or gr["key"] != key:
             if getattr(self, "_graph_warm", None) != key:
@@ -214,18 +219,29 @@ class Trainer:
                 return None
             d = self.diffusion
             net = d._denoise_fn
-            # ONE host-to-device copy per step: the batch (as float32) and the optimizer's step scalars share a buffer
+            dev = self.flat.device
+            # The step's inputs -- the batch (as float32) and the optimizer's eight step scalars -- live in one device
+            # buffer.  The host writes them into one of two PINNED buffers, alternating with the parity of the step word,
+            # and the graph's first node fetches from the one its parity names (clava_stage_fetch_f32).  No
+            # host-synchronous copy sits between two replays: the host prepares step i+1 while step i runs (a pageable
+            # `copy_` waited for step i to finish and left the GPU idle ~40 us per step; asynchronous copies from pinned
+            # memory through the copy engine were slower still, 1.03 vs 0.77 ms/step).  A batch already on the device is
+            # copied device-to-device in stream order and only the scalars go through the pinned buffers.
             B, Dx = x.shape
-            stage_dev = torch.zeros(B * Dx + 8, device=self.flat.device, dtype=torch.float32)
-            static_x = stage_dev[:B * Dx].view(B, Dx)
+            n_x = B * Dx
+            stage_dev = torch.zeros(n_x + 8, device=dev, dtype=torch.float32)
+            static_x = stage_dev[:n_x].view(B, Dx)
             static_x.copy_(x)
-            self._hyper_dev = stage_dev[B * Dx:]
-            stage_host = torch.zeros(B * Dx + 8, dtype=torch.float32)
+            self._hyper_dev = stage_dev[n_x:]
+            pins = [torch.zeros(n_x + 8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            lo = n_x if x.is_cuda else 0                           # first element the fetch node brings in
             # optimizer inside the graph (single process only: data parallel puts an all-reduce between the two halves)
             graph_opt = self.dist is None and os.environ.get("CLAVA_TRAIN_GRAPH_OPT", "1") != "0"
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 st.start_pack(net, d.num_numerical_features + d._sum_k)      # denoiser input width
+                check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self._step_word), ptr(stage_dev[lo:]),
+                                                  c_ll(n_x + 8 - lo), stream_ptr()), "clava_stage_fetch_f32")
                 if _tr.DEVICE_DRAWS:
                     # every draw of the step from the counter-based generator, keyed by (the Trainer's seed, device step word
                     # advanced once per step): the same draws as the eager step, and torch's generator stays out of the graph
@@ -235,18 +251,17 @@ class Trainer:
                     t, noise, u, seed = _tr.draw(d, static_x, None)
                     x_in, idx0, idxt = _tr.noised_input(d, static_x, t, noise, u, seed,
                                                         step_counter=self._step_word if d.has_cat else None)
-                if _tr.DEVICE_DRAWS or d.has_cat:
-                    # the step word advances beside the forward, on the packing stream (joined at the end of the backward)
-                    drawn = torch.cuda.Event()
-                    drawn.record()
-                    side = st.side_stream(self.flat.device)
-                    with torch.cuda.stream(side):
-                        side.wait_event(drawn)
-                        self._step_word.add_(1)
+                # the step word advances beside the forward, on the packing stream (joined at the end of the backward)
+                drawn = torch.cuda.Event()
+                drawn.record()
+                side = st.side_stream(dev)
+                with torch.cuda.stream(side):
+                    side.wait_event(drawn)
+                    self._step_word.add_(1)
                 model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
                 # the loss means are summed on a stream the backward joins at its end: nothing in the step waits for them
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t,
-                                                  aux_stream=st.side_stream(self.flat.device, 1) if _tr.TAIL_BRANCHES else None)
+                                                  aux_stream=st.side_stream(dev, 1) if _tr.TAIL_BRANCHES else None)
                 _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
                 if graph_opt:
                     # ONE update over the whole flat buffer as the graph's last node.  Per-layer updates launched as soon
@@ -255,21 +270,24 @@ class Trainer:
                     # backward they run at 2.9 TB/s instead of 4.2
                     self._adamw_range(0, self.layout.total)
             gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise),
-                                "stage_dev": stage_dev, "stage_host": stage_host, "opt": graph_opt,
-                                "hyper_host": (ctypes.c_float * 8).from_address(stage_host.data_ptr() + 4 * x.numel())}
+                                "stage_dev": stage_dev, "pins": pins, "opt": graph_opt, "ev": [None, None],
+                                "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * n_x) for p in pins]}
+        par = self._host_word & 1
+        if gr["ev"][par] is not None:
+            gr["ev"][par].synchronize()          # the replay two steps back, the last reader of this pinned buffer
         if gr["opt"]:
             check(lib().clava_adamw_hyper_f32(ctypes.c_double(self.lr), ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]),
                                               ctypes.c_double(self.eps), ctypes.c_double(self.weight_decay), c_ll(self.opt_step + 1),
-                                              gr["hyper_host"]), "clava_adamw_hyper_f32")
-            if x.is_cuda:
-                gr["x"].copy_(x)
-                gr["stage_dev"][x.numel():].copy_(gr["stage_host"][x.numel():])
-            else:
-                gr["stage_host"][:x.numel()].view(x.shape).copy_(x)
-                gr["stage_dev"].copy_(gr["stage_host"])
-        else:
+                                              gr["hyper_host"][par]), "clava_adamw_hyper_f32")
+        if x.is_cuda:
             gr["x"].copy_(x)
+        else:
+            gr["pins"][par][:x.numel()].view(x.shape).copy_(x)
         gr["graph"].replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        gr["ev"][par] = ev
+        self._host_word += 1
         st.steps_since += 1
         if gr["opt"]:
             self.opt_step += 1
@@ -316,7 +334,7 @@ class Trainer:
         return {"step": step, "flat": self.flat.clone(), "ema": self.ema_flat.clone(), "m": self.exp_avg.clone(),
                 "v": self.exp_avg_sq.clone(), "opt_step": self.opt_step, "lr": self.lr, "sums": sums.clone(), "count": curr_count,
                 "rows": len(self.loss_history), "rng_cpu": torch.get_rng_state(), "rng_dev": torch.cuda.get_rng_state(dev),
-                "word": self._step_word.clone(),
+                "word": self._step_word.clone(), "host_word": self._host_word,
                 "batches": []}
 
     def _restore(self, snap, sums):
@@ -328,6 +346,7 @@ class Trainer:
         torch.set_rng_state(snap["rng_cpu"])
         torch.cuda.set_rng_state(snap["rng_dev"], self.flat.device)
         self._step_word.copy_(snap["word"])
+        self._host_word = snap["host_word"]
         from .. import split_nets
         split_nets.invalidate()
         return snap["step"], snap["count"]

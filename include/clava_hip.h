@@ -422,6 +422,12 @@ int clava_narrow_wgrad_f32(const float* A, long long lda, int D, const float* Bm
                            float* dw_slabs, long long stride_d, long long stride_j, float* db_narrow_slabs, float* db_wide_slabs,
                            long long slab_stride, void* stream);
 
+/* dst[0..n) = (*word & 1 ? host1 : host0)[0..n): input fetch of a captured training step.  host0 / host1 are pinned,
+ * device-visible HOST buffers (hipHostMalloc / torch pin_memory) that the caller fills alternately, by the parity of the
+ * device step word `word`; the kernel reads them over the bus, so no host-synchronous copy separates two replays.  The
+ * caller must not refill a buffer before the replay that reads it has finished (an event two steps back). */
+int clava_stage_fetch_f32(const float* host0, const float* host1, const unsigned* word, float* dst, long long n, void* stream);
+
 /* The same update with the step-dependent scalars read from device memory, for a step captured in a hipGraph (kernel
  * arguments are frozen at capture): clava_adamw_hyper_f32 fills hyper8[0..7] on the HOST with exactly the values
  * clava_adamw_ema_f32 derives from (lr, betas, eps, weight_decay, step); the caller copies them to the device before each
