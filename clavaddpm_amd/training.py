@@ -263,13 +263,17 @@ class SplitTrainState:
                             [gs[l].abs().max() if gs[l] is not None else zero for l in range(n)] +
                             [x_in.abs().max() if x_in is not None else zero, d_out.abs().max() if d_out is not None else zero])
         v = stats.cpu().tolist()
+        before = (getattr(self, "shift_x", None), getattr(self, "shift_d", None), self.shift_w, self.shift_h, self.shift_g)
         self.shift_x = shift_for(v[3 * n], TARGET_LOG2 + 1)      # the log-one-hot columns are exactly 0 / -69.08
         self.shift_d = shift_for(v[3 * n + 1], TARGET_LOG2)
         self.shift_w = [shift_for(x, 10) for x in v[:n]]
         self.shift_h = [shift_for(x, TARGET_LOG2) for x in v[n:2 * n]]
-        self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:]]
+        self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:3 * n]]
         self.steps_since = 0
-        self.generation += 1
+        # a captured step bakes the scales in: it stays valid while no power-of-two scale moved (the usual case once the
+        # magnitudes have settled; a recapture costs an eager step and a capture, ~8 ms per calibration window)
+        if before != (self.shift_x, self.shift_d, self.shift_w, self.shift_h, self.shift_g):
+            self.generation += 1
 
 
 def wgrad_split_ok(batch, splits=None):

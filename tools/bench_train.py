@@ -18,7 +18,8 @@ for mode in os.environ.get("MODES", "f32,f16x3").split(","):
     for _ in range(5): tr._run_step(data, {"y": y})
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(40): tr._run_step(data, {"y": y})
+    N = int(os.environ.get("STEPS", "40"))
+    for _ in range(N): tr._run_step(data, {"y": y})
     t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
@@ -27,6 +28,6 @@ for mode in os.environ.get("MODES", "f32,f16x3").split(","):
     torch.cuda.synchronize(); L.clava_prof_disable()
     la, ms, fl, by = (ctypes.c_int * nf)(), (ctypes.c_double * nf)(), (ctypes.c_double * nf)(), (ctypes.c_double * nf)()
     L.clava_prof_collect(la, ms, fl, by)
-    print(f"{mode}: wall {t_all/40*1e3:.3f} ms/step, enqueue {t_enq/40*1e3:.3f} ms/step, library kernels {sum(ms)/20:.3f} ms/step")
+    print(f"{mode}: wall {t_all/N*1e3:.3f} ms/step, enqueue {t_enq/N*1e3:.3f} ms/step, library kernels {sum(ms)/20:.3f} ms/step")
     for i in range(nf):
         if la[i]: print(f"    {L.clava_prof_family_name(i).decode():28s} {la[i]/20:5.1f}/step avg {1e3*ms[i]/la[i]:7.1f} us  total {ms[i]/20*1e3:7.1f} us/step")
