@@ -262,13 +262,18 @@ class Trainer:
                 # the loss means are summed on a stream the backward joins at its end: nothing in the step waits for them
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t,
                                                   aux_stream=st.side_stream(dev, 1) if _tr.TAIL_BRANCHES else None)
-                _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st)
+                # The optimizer inside the graph, in two launches: the hidden blocks and the head (99.2 % of the parameters)
+                # as soon as their gradients are complete, on the weight-gradient stream -- an HBM-bound kernel beside the
+                # small latency-bound products of proj and the time-embedding branch that end the backward -- and those
+                # three layers after the join.  (Per-LAYER updates beside the matrix products were measured and are slower,
+                # 0.78-0.82 vs 0.74 ms/step: they slow the L2-bound products by more than their own time.)
+                cut = self.layout.offsets[self.layout.index["proj.weight"]] if graph_opt and _tr.TAIL_BRANCHES else 0
+                assert cut == 0 or all(self.layout.offsets[self.layout.index[n_]] >= cut for n_ in self.layout.names
+                                       if n_.startswith(("proj.", "time_embed."))), "parameter order changed"
+                _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st,
+                                            after_blocks=(lambda: self._adamw_range(0, cut)) if cut > 0 else None)
                 if graph_opt:
-                    # ONE update over the whole flat buffer as the graph's last node.  Per-layer updates launched as soon
-                    # as a layer's gradient is complete were measured and are slower (0.78-0.82 vs 0.74 ms/step): beside
-                    # the products they slow the L2-bound matrix kernels by more than their own time, queued behind the
-                    # backward they run at 2.9 TB/s instead of 4.2
-                    self._adamw_range(0, self.layout.total)
+                    self._adamw_range(cut, self.layout.total)
             gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise),
                                 "stage_dev": stage_dev, "pins": pins, "opt": graph_opt, "ev": [None, None],
                                 "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * n_x) for p in pins]}

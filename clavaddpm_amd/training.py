@@ -366,11 +366,13 @@ def denoiser_forward_split(net, x_in, t, st):
     return out, (x_in, te, z1, a1, hs, hsplit, xs)
 
 
-def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS, on_layer_done=None):
+def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS, on_layer_done=None, after_blocks=None):
     """`denoiser_backward` with the input-gradient products of layers n-2 .. 1 on clava_gemm_f16x3 and the hidden blocks'
     weight / bias gradients on the batch-major split kernel.  `on_layer_done(prefix)` (data parallel) is called with the
     weight-gradient stream current right after a layer's gradient slabs are enqueued: the Trainer reduces them and starts
-    that layer's all-reduce there, beside the rest of the input-gradient chain."""
+    that layer's all-reduce there, beside the rest of the input-gradient chain.  `after_blocks()` is called with that
+    stream current once the gradients of every hidden block and of the head are enqueued on it (the captured step starts
+    their optimizer update there, beside the small products of proj and the time-embedding branch)."""
     x_in, te, z1, a1, hs, hsplit, xs = saved
     wide = xs is not None
     total = layout.total
@@ -466,6 +468,9 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
                                      overflow=st.flag)
         else:                                     # only the float32 gradient is needed
             g = ops.linear_f16x3(gs, wt, out_f32=True, overflow=st.flag)
+    if after_blocks is not None:
+        with torch.cuda.stream(side):
+            after_blocks()
     # the end of the backward is five small products that only share g (and d_z1): three parallel branches instead of a
     # queue behind the hidden blocks' weight gradients -- proj on stream 1, time_embed.2 on stream 2, the chain
     # d_a1 -> d_z1 -> time_embed.0 on the main stream
