@@ -25,6 +25,7 @@ WIDE_END_LAYERS = int(os.environ.get("CLAVA_WIDE_END_LAYERS", "256"))   # D_in f
 FRONT_FUSED = os.environ.get("CLAVA_TRAIN_FRONT", "1") != "0"   # time MLP + proj + split pack of the training forward in one launch
 DEVICE_DRAWS = os.environ.get("CLAVA_TRAIN_DRAWS", "device") != "torch"   # captured step: t / noise from the in-kernel generator
 NARROW_ENDS = os.environ.get("CLAVA_TRAIN_NARROW", "1") != "0"   # head / proj of tables with <= 16 columns on the memory-bound kernels
+WGRAD_DEFER = os.environ.get("CLAVA_WGRAD_DEFER", "0") != "0"   # hidden-block weight gradients after the input-gradient chain (measured: slower)
 TAIL_BRANCHES = os.environ.get("CLAVA_TAIL_BRANCHES", "1") != "0"   # proj / time-embedding gradients on parallel streams
 GRAD_SPLITS = int(os.environ.get("CLAVA_GRAD_SPLITS", "8"))   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
@@ -452,8 +453,17 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
         param_grads_async(names[n - 1], d_out, hs[n - 2])
         g = ops.linear_dgrad(d_out, ws[n - 1].detach(), act_out=hs[n - 2], slope=0.0)
         gs = ops.split_pack(g, st.shift_g[n - 2], st.flag, out=st.buf(("g", n - 2), M, g.shape[1], dev))
+    # A workgroup of either product family fills a CU's LDS, so an input-gradient product and a weight-gradient product in
+    # flight together only take turns on the CUs and the input-gradient chain runs at half speed beside the weight
+    # gradients.  Enqueueing the weight gradients AFTER the chain (CLAVA_WGRAD_DEFER=1) was measured and is slower all the
+    # same (0.660 vs 0.644 ms/step): side by side, each family fills the other's write-drain gaps between dependent kernels.
+    deferred = []
+    defer = WGRAD_DEFER and on_layer_done is None
     for l in range(n - 2, 0, -1):
-        param_grads_async(names[l], g, hs[l - 1], gs, hsplit[l - 1])
+        if defer:
+            deferred.append((names[l], g, hs[l - 1], gs, hsplit[l - 1]))
+        else:
+            param_grads_async(names[l], g, hs[l - 1], gs, hsplit[l - 1])
         w = ws[l]
         wt = st.bufs[("wt", l)]                   # W^T for the input gradient, packed with the forward operand (pack_weights)
         if l - 1 >= 1 and split_wgrad:            # weight and bias gradients of layer l-1 read the planes: no float32 copy
@@ -468,6 +478,8 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
                                      overflow=st.flag)
         else:                                     # only the float32 gradient is needed
             g = ops.linear_f16x3(gs, wt, out_f32=True, overflow=st.flag)
+    for args in deferred:
+        param_grads_async(*args)
     if after_blocks is not None:
         with torch.cuda.stream(side):
             after_blocks()
