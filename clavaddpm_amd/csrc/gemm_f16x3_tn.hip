@@ -143,40 +143,76 @@ __global__ void __launch_bounds__(512) gemm_f16x3_tn_kernel(SplitGemmArgs g) {
 #pragma unroll
         for (int q = 0; q < NI; ++q) glds16(src[q] + k * (q < 2 * IA ? stepA : stepW), st + stage * STAGE + q * IMG);
     };
+    // the same DMAs one group at a time (images q = part, part + TN, ...), placed between the MFMA groups of the main loop:
+    // an LDS-DMA holds the wave's issue port for ~100 cycles, and all NI of them in a row at the top of an iteration -- in
+    // both waves of a SIMD at once, right after the barrier -- left the matrix pipe idle for as long as a k block's MFMAs
+    // take (measured: 1.84 us per k block with every CU busy against 0.9 us of MFMA work)
+    auto issue_part = [&](int kb, int stage, int part) {
+        const int k = min(kb, nkb - 1);
+#pragma unroll
+        for (int q = part; q < NI; q += TN) glds16(src[q] + k * (q < 2 * IA ? stepA : stepW), st + stage * STAGE + q * IMG);
+    };
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0, s0);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NI * (NS - 2)) : "memory");
 
-    int cur = 0, nxt = NS - 1;
-    for (int kb = 0; kb < nkb; ++kb) {
-        issue(kb + NS - 1, nxt);
-        const char* img = smem + cur * STAGE;
-        h8 dh[TM], dl[TM];
+    // Main loop, software pipelined over the fragment reads: the operand fragments of MFMA group i+1 are read from LDS
+    // while group i multiplies, and the dy fragments + first x fragment of the NEXT k block while the last group does.
+    // (With every group's reads in front of its own MFMAs, and one barrier per k block after the last group, a k block
+    // took ~2550 cycles for 1536 cycles of MFMA work per SIMD: each group exposed an LDS round trip.)  The barrier
+    // therefore sits before the last group: by then this wave has read everything it needs from stage kb (lgkmcnt(0)),
+    // so after the barrier stage kb's buffer may be refilled (the DMAs of the next iteration) and stage kb+1, whose DMAs
+    // every wave has waited for, may be read.
+    constexpr int LAST_PART = (NI > TN - 1) ? (NI - (TN - 1) + TN - 1) / TN : 0;      // DMAs issued with the last group
+    auto d_frags = [&](const char* img, h8 (&dh)[TM], h8 (&dl)[TM]) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             dh[j] = tr_frag(img, ad[j][0], ad[j][1]);
             dl[j] = tr_frag(img + IA * IMG, ad[j][0], ad[j][1]);
         }
-        if (colsum) {                                         // wave-uniform
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, dl[j], accb[j], 0, 0, 0);
-                accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, dh[j], accb[j], 0, 0, 0);
-            }
-        }
+    };
+    int cur = 0, nxt = NS - 1;
+    h8 dh[TM], dl[TM];
+    d_frags(smem, dh, dl);
+    h8 wh = tr_frag(smem, aw[0][0], aw[0][1]), wl = tr_frag(smem + IW * IMG, aw[0][0], aw[0][1]);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const char* img = smem + cur * STAGE;
+        const char* imgn = smem + ((cur + 1 == NS) ? 0 : cur + 1) * STAGE;
+        h8 dhn[TM], dln[TM];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const h8 wh = tr_frag(img, aw[i][0], aw[i][1]);
-            const h8 wl = tr_frag(img + IW * IMG, aw[i][0], aw[i][1]);
+            h8 whn, wln;
+            if (i + 1 < TN) {
+                whn = tr_frag(img, aw[i + 1][0], aw[i + 1][1]);
+                wln = tr_frag(img + IW * IMG, aw[i + 1][0], aw[i + 1][1]);
+            } else {                                          // past the barrier: the next k block's first fragments
+                d_frags(imgn, dhn, dln);
+                whn = tr_frag(imgn, aw[0][0], aw[0][1]);
+                wln = tr_frag(imgn + IW * IMG, aw[0][0], aw[0][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0 && colsum) {                           // wave-uniform
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, dl[j], accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, dh[j], accb[j], 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, dh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, dl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, dh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_part(kb + NS - 1, nxt, i);
+            if (i == TN - 2)        // stage kb+1 has landed: only younger stages and this iteration's DMAs may be in flight
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI * (NS - 3) + NI - LAST_PART) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            wh = whn; wl = wln;
         }
-        // this wave's share of stage kb+1 has landed and every wave is done reading stage kb before it is refilled
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI * (NS - 2)) : "memory");
+#pragma unroll
+        for (int j = 0; j < TM; ++j) { dh[j] = dhn[j]; dl[j] = dln[j]; }
         nxt = cur;
         cur = (cur + 1 == NS) ? 0 : cur + 1;
     }

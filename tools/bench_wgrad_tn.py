@@ -16,7 +16,8 @@ def timeit(fn, n=50, w=5):
 
 M = int(os.environ.get("M", "4096"))
 g = torch.Generator(device="cuda").manual_seed(0)
-for (N, K) in [(1024, 1024), (1024, 512), (512, 1024), (512, 128), (128, 8397)]:
+SHAPES = [(1024, 1024), (1024, 512), (512, 1024), (512, 128), (128, 8397)][:int(os.environ.get("NSHAPES", "5"))]
+for (N, K) in SHAPES:
     dy = ops.split_pack(torch.randn(M, N, device="cuda", generator=g) * 0.01, 12)
     x = ops.split_pack(torch.randn(M, K, device="cuda", generator=g), 4)
     S = int(os.environ.get("S", "8"))
