@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) cat_input_kernel(CatInputArgs a) {
         for (int c0 = 0; c0 < a.d1; c0 += 128) {
             const int j = c0 + 2 * lane;
             f2 base = ld2(a.cat_bias + j);
-            if (a.emb) { const f2 e = ld2(a.emb + j); base.x += e.x; base.y += e.y; }
+            if (a.emb && a.ld_emb == 0) { const f2 e = ld2(a.emb + j); base.x += e.x; base.y += e.y; }
             f2 num[ROWS], hot[ROWS];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) num[r] = hot[r] = f2{0.f, 0.f};
@@ -91,6 +91,11 @@ __global__ void __launch_bounds__(256) cat_input_kernel(CatInputArgs a) {
                 const int row = row0 + r;
                 if (row >= a.B) continue;
                 float v[2] = {(base.x + num[r].x) - a.log_tiny * hot[r].x, (base.y + num[r].y) - a.log_tiny * hot[r].y};
+                if (a.emb && a.ld_emb) { const f2 e = ld2(a.emb + (size_t)row * a.ld_emb + j); v[0] += e.x; v[1] += e.y; }
+                if (a.out_f32) {
+                    const float y0 = fmaxf(v[0], v[0] * slope), y1 = fmaxf(v[1], v[1] * slope);
+                    *reinterpret_cast<float2*>(a.out_f32 + (size_t)row * a.ld_f32 + j) = make_float2(y0, y1);
+                }
                 _Float16 hi[2], lo[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -109,6 +114,21 @@ __global__ void __launch_bounds__(256) cat_input_kernel(CatInputArgs a) {
 }
 
 }  // namespace
+
+extern "C" int clava_cat_input_f32(const float* xnum, int ld_x, const int* idx, int B, int n_num, int m, int d1, const int* offsets,
+                                   const float* num_wt, const float* cat_wt, const float* cat_bias, const float* emb, long long ld_emb,
+                                   float log_tiny, int act, void* out_split, long long pitch, int shift, float* out_f32,
+                                   long long ld_f32, int* overflow, void* stream) {
+    CLAVA_CHECK_ARG(out_split && pitch >= 4LL * d1 && pitch % 8 == 0 && shift >= -24 && shift <= 24, "cat_input: bad split output");
+    CLAVA_CHECK_ARG(!emb || ld_emb == 0 || (ld_emb >= d1 && ld_emb % 2 == 0), "cat_input: embedding rows must be >= d1 floats, 8-byte aligned");
+    CLAVA_CHECK_ARG(!out_f32 || (ld_f32 >= d1 && ld_f32 % 2 == 0), "cat_input: float32 output rows must be >= d1 floats, 8-byte aligned");
+    CatInputArgs a = {};
+    a.xnum = xnum; a.ld_x = ld_x; a.idx = idx; a.B = B; a.n_num = n_num; a.m = m; a.d1 = d1; a.offsets = offsets;
+    a.num_wt = num_wt; a.cat_wt = cat_wt; a.cat_bias = cat_bias; a.emb = emb; a.ld_emb = ld_emb; a.log_tiny = log_tiny; a.act = act;
+    a.out = (char*)out_split; a.pitch_out = pitch; a.scale_out = ldexpf(1.f, shift); a.out_f32 = out_f32; a.ld_f32 = ld_f32;
+    a.overflow = overflow;
+    return clava_launch_cat_input(a, (hipStream_t)stream);
+}
 
 int clava_launch_cat_input(const CatInputArgs& a, hipStream_t stream) {
     CLAVA_CHECK_ARG(a.B > 0 && a.m > 0 && a.d1 > 0 && a.d1 % 128 == 0 && a.n_num >= 0, "cat_input: bad shape B=%d m=%d d1=%d", a.B, a.m, a.d1);

@@ -700,7 +700,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 rc = split_forward_range(d, 2, nd - 2, outs[1], R, outs, overflow, G.den);
                 if (rc) return rc;
             } else if (cat_gather) {
-                CatInputArgs ca;
+                CatInputArgs ca = {};
                 ca.xnum = w.x_in + (size_t)r0 * c->n_num; ca.ld_x = c->n_num;
                 ca.idx = idx + (size_t)r0 * c->m;
                 ca.B = R; ca.n_num = c->n_num; ca.m = c->m; ca.d1 = d->dims[1];

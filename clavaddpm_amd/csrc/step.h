@@ -60,7 +60,9 @@ struct CatInputArgs {
     const float* num_wt;                  // [n_num][d1]: numeric columns of the layer's weight, transposed
     const float* cat_wt;                  // [sumK][d1]: categorical columns, transposed (one gathered row per feature)
     const float* cat_bias;                // [d1]: b + log(1e-30) * (row sums of the categorical columns)
-    const float* emb;                     // [d1] broadcast time-embedding row or null
+    const float* emb;                     // time embedding or null: one broadcast row [d1] (ld_emb = 0, the sampling chain:
+    long long ld_emb;                     //   one t per launch) or a row per batch row (ld_emb = its stride; training)
+    float* out_f32; long long ld_f32;     // optional float32 copy of the layer output [B, d1] (null: split rows only)
     float log_tiny;                       // log(1e-30) as float32 (tab_ddpm/utils.py:131)
     int act;
     char* out; long long pitch_out;       // split rows [B, d1]

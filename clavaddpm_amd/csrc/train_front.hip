@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) train_front_kernel(FrontArgs a) {
         for (int i = 0; i < 8; ++i) acc[i] = b;
     }
     fma_rows(acc, act1, wl, c, half, DT / 4);
-    const float bp = a.bp[c];
+    const float bp = a.bp ? a.bp[c] : 0.f;                    // no proj: h = emb (the caller's first layer adds the rest)
     bool ovf = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -174,8 +174,10 @@ extern "C" int clava_train_front_f32(const long long* t, int B, const float* fre
                                      const float* bp, float* te, float* z1, float* a1, float* h, void* h_split, long long pitch,
                                      int shift, int* overflow, void* stream) {
     CLAVA_CHECK_ARG(dim_t == DT, "train_front: dim_t %d not supported (the fused front is built for 128)", dim_t);
-    CLAVA_CHECK_ARG(t && freqs && x_in && w0 && b0 && w2 && b2 && wp && bp && te && z1 && a1 && (h || h_split), "train_front: null operand");
-    CLAVA_CHECK_ARG(B > 0 && d_in > 0 && ldx >= d_in, "train_front: bad shape B=%d d_in=%d ldx=%lld", B, d_in, ldx);
+    CLAVA_CHECK_ARG(t && freqs && w0 && b0 && w2 && b2 && te && z1 && a1 && (h || h_split), "train_front: null operand");
+    CLAVA_CHECK_ARG(B > 0 && d_in >= 0 && (d_in == 0 || (x_in && wp && bp && ldx >= d_in)), "train_front: bad shape B=%d d_in=%d ldx=%lld", B,
+                    d_in, ldx);
+    if (d_in == 0) wp = bp = nullptr;
     if (h_split) {
         CLAVA_CHECK_ARG(pitch >= 4LL * DT && pitch % 8 == 0 && (reinterpret_cast<unsigned long long>(h_split) & 7) == 0,
                         "train_front: split pitch %lld too small or misaligned", pitch);

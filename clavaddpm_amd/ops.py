@@ -230,10 +230,11 @@ def linear_wgrad_f16x3(dyt, xt, splits, out, slab_stride, tile_config=-1):
     return splits
 
 
-def linear_wgrad_f16x3_tn(dy, x, splits, out, slab_stride, bias_out=None):
+def linear_wgrad_f16x3_tn(dy, x, splits, out, slab_stride, bias_out=None, ldw=None):
     """`linear_wgrad_f16x3` from the batch-major SplitTensors themselves (clava_gemm_wgrad_f16x3_tn): dy [M, N_out],
     x [M, K_in], M a multiple of 32; no transposed copies.  `bias_out` (slabs, same stride) also receives the column sums
-    of dy (the bias gradient)."""
+    of dy (the bias gradient).  `ldw`: row stride of the gradient in `out` (default K_in; larger when x holds only the
+    first columns of the layer's input)."""
     M, n_out = dy.rows, dy.cols
     k_in = x.cols
     if x.rows != M or M % 32:
@@ -242,7 +243,7 @@ def linear_wgrad_f16x3_tn(dy, x, splits, out, slab_stride, bias_out=None):
     while splits > 1 and (splits - 1) * ((nkb + splits - 1) // splits) >= nkb:
         splits -= 1
     check(lib().clava_gemm_wgrad_f16x3_tn(ptr(dy.buf), _lib.c_long(dy.pitch), c_int(dy.shift), ptr(x.buf), _lib.c_long(x.pitch),
-                                          c_int(x.shift), ptr(out), c_int(k_in), _lib.c_long(slab_stride), ptr(bias_out), c_int(M),
+                                          c_int(x.shift), ptr(out), c_int(k_in if ldw is None else ldw), _lib.c_long(slab_stride), ptr(bias_out), c_int(M),
                                           c_int(n_out), c_int(k_in), c_int(splits), stream_ptr()), "clava_gemm_wgrad_f16x3_tn")
     return splits
 

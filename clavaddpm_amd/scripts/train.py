@@ -192,7 +192,7 @@ class Trainer:
             gs = [None] * len(saved[4]) if st is not None else None
             _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs, collect=gs)
             if st is not None:
-                st.calibrate(net.stack()[0], saved[4], gs, x_in=x_in, d_out=d_out)
+                st.calibrate(net.stack()[0], saved[4], gs, x_in=x_in, d_out=d_out, n_num=d.num_numerical_features)
         else:
             model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
             loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
@@ -238,14 +238,22 @@ class Trainer:
             # optimizer inside the graph (single process only: data parallel puts an all-reduce between the two halves)
             graph_opt = self.dist is None and os.environ.get("CLAVA_TRAIN_GRAPH_OPT", "1") != "0"
             graph = torch.cuda.CUDAGraph()
+            # wide tables with categorical columns: proj and its weight gradient from (numeric columns, class indices),
+            # the [B, sum K] log-one-hot image is never built (csrc/cat_input.hip, csrc/cat_wgrad.hip)
+            gather = st.gather_ok(d, net, B)
+            if gather:
+                st.gather_plan(d, dev)
+                st.gather_weights(net.stack()[0][0].detach(), net.stack()[1][0].detach(), d.num_numerical_features)   # allocates
+                st.pack_weights(net.stack()[0], True, dev, gather=True)      # builds the packing plan (an upload: not capturable)
             with torch.cuda.graph(graph):
-                st.start_pack(net, d.num_numerical_features + d._sum_k)      # denoiser input width
+                st.start_pack(net, d.num_numerical_features + d._sum_k,      # denoiser input width
+                              gather_n_num=d.num_numerical_features if gather else None)
                 check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self._step_word), ptr(stage_dev[lo:]),
                                                   c_ll(n_x + 8 - lo), stream_ptr()), "clava_stage_fetch_f32")
                 if _tr.DEVICE_DRAWS:
                     # every draw of the step from the counter-based generator, keyed by (the Trainer's seed, device step word
                     # advanced once per step): the same draws as the eager step, and torch's generator stays out of the graph
-                    t, noise, x_in, idx0, idxt = _tr.draw_noised_input(d, static_x, self._draw_seed, self._step_word)
+                    t, noise, x_in, idx0, idxt = _tr.draw_noised_input(d, static_x, self._draw_seed, self._step_word, dense=not gather)
                 else:
                     # t and the Gaussian noise from torch's graph-safe generator; the categorical draws keyed as above
                     t, noise, u, seed = _tr.draw(d, static_x, None)
@@ -258,7 +266,7 @@ class Trainer:
                 with torch.cuda.stream(side):
                     side.wait_event(drawn)
                     self._step_word.add_(1)
-                model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
+                model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st, cat=(idxt, d) if gather else None)
                 # the loss means are summed on a stream the backward joins at its end: nothing in the step waits for them
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t,
                                                   aux_stream=st.side_stream(dev, 1) if _tr.TAIL_BRANCHES else None)

@@ -13,6 +13,8 @@ Mirrors `mixed_loss` (`tab_ddpm/gaussian_multinomial_diffsuion.py:636-675`) and 
 import ctypes
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib, ops
@@ -26,6 +28,7 @@ FRONT_FUSED = os.environ.get("CLAVA_TRAIN_FRONT", "1") != "0"   # time MLP + pro
 DEVICE_DRAWS = os.environ.get("CLAVA_TRAIN_DRAWS", "device") != "torch"   # captured step: t / noise from the in-kernel generator
 NARROW_ENDS = os.environ.get("CLAVA_TRAIN_NARROW", "1") != "0"   # head / proj of tables with <= 16 columns on the memory-bound kernels
 WGRAD_DEFER = os.environ.get("CLAVA_WGRAD_DEFER", "0") != "0"   # hidden-block weight gradients after the input-gradient chain (measured: slower)
+CAT_GATHER = os.environ.get("CLAVA_TRAIN_CAT_GATHER", "1") != "0"   # wide tables: first layer and its weight gradient from (numeric columns, category indices)
 TAIL_BRANCHES = os.environ.get("CLAVA_TAIL_BRANCHES", "1") != "0"   # proj / time-embedding gradients on parallel streams
 GRAD_SPLITS = int(os.environ.get("CLAVA_GRAD_SPLITS", "8"))   # batch ranges per weight-gradient product (4096-row batches -> 512 rows per slab, >= 512 workgroups)
 
@@ -210,14 +213,14 @@ class SplitTrainState:
             self.bufs[key] = b
         return b
 
-    def pack_weights(self, ws, wide, device):
+    def pack_weights(self, ws, wide, device, gather=False):
         """Packs the step's weights for both products in one launch (ops.PackPlan): layers 1 .. n-2 as the forward operand
         ("w", l) and, transposed, as the input-gradient operand ("wt", l); for wide tables also proj (forward only) and the
         head (both).  The plan is rebuilt when a weight's storage or a scale changed."""
         n = len(ws)
         layers = [(l, True) for l in range(1, n - 1)]
         if wide:
-            layers = [(0, False)] + layers + [(n - 1, True)]
+            layers = ([] if gather else [(0, False)]) + layers + [(n - 1, True)]
         key = tuple((ws[l].data_ptr(), self.shift_w[l]) for l, _ in layers)
         plan = getattr(self, "_pack_plan", None)
         if plan is None or plan.key != key:
@@ -233,10 +236,48 @@ class SplitTrainState:
         """Whether proj / head of a `d_in`-column table run on the split-f16 kernels too."""
         return WIDE_END_LAYERS > 0 and d_in >= WIDE_END_LAYERS and getattr(self, "shift_x", None) is not None
 
-    def start_pack(self, net, d_in):
+    # ---- gather form of the first layer (tables with categorical columns, wide input) ---------------------------------
+    def gather_ok(self, diffusion, net, batch):
+        """Whether a step of `batch` rows runs proj from (numeric columns, category indices) (csrc/cat_input.hip) and its
+        weight gradient from csrc/cat_wgrad.hip instead of products over the [B, sum K] log-one-hot image."""
+        d_in = diffusion.num_numerical_features + diffusion._sum_k
+        w0 = net.stack()[0][0]
+        return (CAT_GATHER and DEVICE_DRAWS and diffusion.has_cat and self.wide(d_in) and net.dim_t == 128 and tuple(w0.shape) == (128, d_in)
+                and getattr(self, "shift_xn", None) is not None and wgrad_split_ok(batch) and batch % 32 == 0)
+
+    def gather_plan(self, diffusion, device):
+        """Per-table constants of the gather form: device offsets, the weight-gradient kernel's workgroup plan, log(1e-30)."""
+        gp = getattr(self, "_gather_plan", None)
+        if gp is None:
+            off = np.ascontiguousarray(diffusion._offsets_i32.cpu().numpy().astype(np.int32))
+            m = len(off) - 1
+            op = off.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+            nwg = lib().clava_cat_wgrad_workgroups(op, c_int(m))
+            wf, wk = np.zeros(nwg, np.int32), np.zeros(nwg, np.int32)
+            check(lib().clava_cat_wgrad_plan(op, c_int(m), wf.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                             wk.ctypes.data_as(ctypes.POINTER(ctypes.c_int))), "clava_cat_wgrad_plan")
+            gp = self._gather_plan = {"m": m, "nwg": nwg, "wf": torch.from_numpy(wf).to(device), "wk": torch.from_numpy(wk).to(device),
+                                      "log_tiny": float(torch.log(torch.tensor(1e-30, dtype=torch.float32)))}
+        return gp
+
+    def gather_weights(self, w0, b0, n_num):
+        """proj's weight transposed ([D_in][128]: rows = input columns) and its bias with the constant part of the
+        log-one-hot columns folded in, b + log(1e-30) * (row sums of the categorical columns), into persistent buffers
+        (a captured step rebuilds them every replay: the weights change every step)."""
+        D = w0.shape[1]
+        if getattr(self, "_wt0", None) is None or self._wt0.shape[0] != D:
+            self._wt0 = torch.empty((D, w0.shape[0]), device=w0.device, dtype=torch.float32)
+            self._cat_bias = torch.empty(w0.shape[0], device=w0.device, dtype=torch.float32)
+        log_tiny = float(torch.log(torch.tensor(1e-30, dtype=torch.float32)))
+        self._wt0.copy_(w0.t())
+        self._cat_bias.copy_(b0.double() + log_tiny * w0[:, n_num:].sum(dim=1, dtype=torch.float64))
+
+    def start_pack(self, net, d_in, gather_n_num=None):
         """Starts this step's weight packing on stream 0 of the parallel branches, forked from the current stream: the
         packing only depends on the weights, so a step calls this before it draws t and the noise and the packing runs
-        beside the whole front of the step.  `denoiser_forward_split` joins it before its first split product."""
+        beside the whole front of the step.  `denoiser_forward_split` joins it before its first split product.
+        `gather_n_num`: the step runs proj in gather form (number of numeric columns); its weight operands are rebuilt
+        here instead of proj's packed planes."""
         ws = net.stack()[0]
         dev = ws[0].device
         main = torch.cuda.current_stream()
@@ -245,13 +286,16 @@ class SplitTrainState:
         fork.record(main)
         with torch.cuda.stream(side):
             side.wait_event(fork)
-            self.pack_weights(ws, self.wide(d_in), dev)   # every weight operand of this step's forward and input-gradient products
+            self.pack_weights(ws, self.wide(d_in), dev, gather=gather_n_num is not None)   # every weight operand of this step's products
+            if gather_n_num is not None:
+                self.gather_weights(ws[0].detach(), net.stack()[1][0].detach(), gather_n_num)
             self._packed = torch.cuda.Event()
             self._packed.record(side)
 
-    def calibrate(self, ws, hs, gs, x_in=None, d_out=None):
+    def calibrate(self, ws, hs, gs, x_in=None, d_out=None, n_num=None):
         """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step;
-        x_in / d_out (denoiser input, loss gradient) fix the scales of the wide end layers' operands."""
+        x_in / d_out (denoiser input, loss gradient) fix the scales of the wide end layers' operands; `n_num` (numeric
+        columns at the front of x_in) fixes the scale of the numeric block alone (gather form of the first layer)."""
         from .split_nets import TARGET_LOG2, shift_for
         n = len(ws)
         if self.flag is None:
@@ -262,18 +306,21 @@ class SplitTrainState:
         zero = torch.zeros((), device=ws[0].device)
         stats = torch.stack([w.detach().abs().max() for w in ws] + [h.abs().max() for h in hs] +
                             [gs[l].abs().max() if gs[l] is not None else zero for l in range(n)] +
-                            [x_in.abs().max() if x_in is not None else zero, d_out.abs().max() if d_out is not None else zero])
+                            [x_in.abs().max() if x_in is not None else zero, d_out.abs().max() if d_out is not None else zero,
+                             x_in[:, :n_num].abs().max() if x_in is not None and n_num else zero])
         v = stats.cpu().tolist()
-        before = (getattr(self, "shift_x", None), getattr(self, "shift_d", None), self.shift_w, self.shift_h, self.shift_g)
+        before = (getattr(self, "shift_x", None), getattr(self, "shift_d", None), getattr(self, "shift_xn", None), self.shift_w,
+                  self.shift_h, self.shift_g)
         self.shift_x = shift_for(v[3 * n], TARGET_LOG2 + 1)      # the log-one-hot columns are exactly 0 / -69.08
         self.shift_d = shift_for(v[3 * n + 1], TARGET_LOG2)
+        self.shift_xn = shift_for(v[3 * n + 2], TARGET_LOG2) if (x_in is not None and n_num) else None
         self.shift_w = [shift_for(x, 10) for x in v[:n]]
         self.shift_h = [shift_for(x, TARGET_LOG2) for x in v[n:2 * n]]
         self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:3 * n]]
         self.steps_since = 0
         # a captured step bakes the scales in: it stays valid while no power-of-two scale moved (the usual case once the
         # magnitudes have settled; a recapture costs an eager step and a capture, ~8 ms per calibration window)
-        if before != (self.shift_x, self.shift_d, self.shift_w, self.shift_h, self.shift_g):
+        if before != (self.shift_x, self.shift_d, self.shift_xn, self.shift_w, self.shift_h, self.shift_g):
             self.generation += 1
 
 
@@ -285,16 +332,19 @@ def wgrad_split_ok(batch, splits=None):
     return WGRAD_F16X3 and (splits - 1) * ((nkb + splits - 1) // splits) < nkb
 
 
-def denoiser_forward_split(net, x_in, t, st):
-    """`denoiser_forward` with the hidden blocks (layers 1 .. n-2 of the stack) on clava_gemm_f16x3."""
+def denoiser_forward_split(net, x_in, t, st, cat=None):
+    """`denoiser_forward` with the hidden blocks (layers 1 .. n-2 of the stack) on clava_gemm_f16x3.
+    `cat` = (idx [B, m] int32 noised categories, diffusion): x_in then holds the NUMERIC columns only and proj runs in
+    gather form (csrc/cat_input.hip; the caller checked `st.gather_ok` and started the packing with `gather_n_num`)."""
     ws, bs, acts = net.stack()
     dev = x_in.device
-    wide = st.wide(x_in.shape[1])
+    d_in = ws[0].shape[1] if cat is not None else x_in.shape[1]
+    wide = st.wide(d_in)
     # the weight packing runs on a second stream (a parallel branch of the captured graph), started by the caller before
     # the draws or here, and is joined before the first split product
     main = torch.cuda.current_stream()
     if getattr(st, "_packed", None) is None:
-        st.start_pack(net, x_in.shape[1])
+        st.start_pack(net, d_in, gather_n_num=x_in.shape[1] if cat is not None else None)
     packed, st._packed = st._packed, None
     w0, b0 = net.time_embed[0].weight.detach(), net.time_embed[0].bias.detach()
     w2, b2 = net.time_embed[2].weight.detach(), net.time_embed[2].bias.detach()
@@ -304,9 +354,31 @@ def denoiser_forward_split(net, x_in, t, st):
     # D_in-wide end layers (one-hot heavy tables, BASELINE.json configs[4]) go to the f16 matrix cores too; at a handful
     # of columns they are a few MFLOP and stay on the float32 kernels
     xs = None
+    catinfo = None
     fused_front = (FRONT_FUSED and not wide and net.dim_t == 128 and tuple(ws[0].shape) == (128, x_in.shape[1])
                    and t.dtype == torch.int64 and x_in.stride(1) == 1)
-    if fused_front:
+    if cat is not None:
+        # time MLP alone (clava_train_front_f32 without proj), then proj from the numeric columns and m gathered weight rows
+        from .tab_ddpm.modules import _freqs
+        idx, diffusion = cat
+        gp = st.gather_plan(diffusion, dev)
+        n_num = x_in.shape[1]
+        te, z1, a1, emb = (torch.empty((B, 128), device=dev, dtype=torch.float32) for _ in range(4))
+        check(lib().clava_train_front_f32(ptr(t.contiguous()), c_int(B), ptr(_freqs(128, dev)), c_int(128), None, c_ll(0), c_int(0),
+                                          ptr(w0), ptr(b0), ptr(w2), ptr(b2), None, None, ptr(te), ptr(z1), ptr(a1), ptr(emb), None,
+                                          c_ll(0), c_int(0), None, stream_ptr()), "clava_train_front_f32(emb)")
+        main.wait_event(packed)                   # the transposed weight and the folded bias come from the packing stream
+        h = None if planes_only else torch.empty((B, 128), device=dev, dtype=torch.float32)
+        hsp = st.buf(("h", 0), B, 128, dev)
+        hsp.shift = st.shift_h[0]
+        check(lib().clava_cat_input_f32(ptr(x_in), c_int(x_in.stride(0)), ptr(idx), c_int(B), c_int(n_num), c_int(gp["m"]), c_int(128),
+                                        ptr(diffusion._offsets_i32), ptr(st._wt0), ptr(st._wt0[n_num:]), ptr(st._cat_bias), ptr(emb),
+                                        c_ll(128), c_float(gp["log_tiny"]), c_int(0), ptr(hsp.buf), c_ll(hsp.pitch), c_int(hsp.shift),
+                                        ptr(h), c_ll(128), ptr(st.flag), stream_ptr()), "clava_cat_input_f32")
+        hs = [h]
+        hsplit = [hsp]
+        catinfo = (idx, diffusion, gp)
+    elif fused_front:
         # timestep embedding, time MLP, proj and the split pack of h in one launch (csrc/train_front.hip)
         from .tab_ddpm.modules import _freqs
         te, z1, a1 = (torch.empty((B, 128), device=dev, dtype=torch.float32) for _ in range(3))
@@ -364,7 +436,7 @@ def denoiser_forward_split(net, x_in, t, st):
     else:
         out = ops.linear(hs[-1], ws[n - 1].detach(), bs[n - 1].detach())
     hs.append(out)
-    return out, (x_in, te, z1, a1, hs, hsplit, xs)
+    return out, (x_in, te, z1, a1, hs, hsplit, xs, catinfo)
 
 
 def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS, on_layer_done=None, after_blocks=None):
@@ -374,8 +446,8 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     that layer's all-reduce there, beside the rest of the input-gradient chain.  `after_blocks()` is called with that
     stream current once the gradients of every hidden block and of the head are enqueued on it (the captured step starts
     their optimizer update there, beside the small products of proj and the time-embedding branch)."""
-    x_in, te, z1, a1, hs, hsplit, xs = saved
-    wide = xs is not None
+    x_in, te, z1, a1, hs, hsplit, xs, catinfo = saved
+    wide = xs is not None or catinfo is not None
     total = layout.total
     M = d_out.shape[0]
     dev = d_out.device
@@ -487,7 +559,32 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     # queue behind the hidden blocks' weight gradients -- proj on stream 1, time_embed.2 on stream 2, the chain
     # d_a1 -> d_z1 -> time_embed.0 on the main stream
     tail = [st.side_stream(dev, 1), st.side_stream(dev, 2)] if TAIL_BRANCHES else [side, side]
-    if wide:
+    if catinfo is not None:
+        # proj in gather form: numeric columns of dW (and the bias) from the batch-major split kernel on the numeric block,
+        # categorical columns from the class-wise row sums of g (csrc/cat_wgrad.hip); the split image of x_in does not exist
+        idx, diffusion, gp = catinfo
+        n_num = x_in.shape[1]
+        wi, bi = layout.index["proj.weight"], layout.index["proj.bias"]
+        D = layout.shapes[wi][1]
+        wsl, bsl = slabs[:, layout.offsets[wi]:], slabs[:, layout.offsets[bi]:]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        keep.append((g, gs, x_in, idx))
+        with torch.cuda.stream(tail[0]):
+            tail[0].wait_event(ev)
+            if n_num > 0:
+                xn = ops.split_pack(x_in, st.shift_xn, st.flag, out=st.buf(("xn",), M, n_num, dev))
+                ops.linear_wgrad_f16x3_tn(gs, xn, splits, wsl, total, bias_out=bsl, ldw=D)
+            else:
+                check(lib().clava_colsum_slabs_split(ptr(gs.buf), c_ll(gs.pitch), c_int(gs.shift), c_int(M), c_int(gs.cols), c_int(splits),
+                                                     ptr(bsl), c_ll(total), stream_ptr()), "clava_colsum_slabs_split")
+            check(lib().clava_cat_wgrad_f32(ptr(g), c_ll(g.stride(0)), ptr(bsl), c_int(M), c_int(128), ptr(idx), c_int(gp["m"]),
+                                            ptr(diffusion._offsets_i32), ptr(gp["wf"]), ptr(gp["wk"]), c_int(gp["nwg"]), c_int(splits),
+                                            c_float(gp["log_tiny"]), ptr(wsl), c_ll(D), c_int(n_num), c_ll(total), stream_ptr()),
+                  "clava_cat_wgrad_f32")
+            if on_layer_done is not None:
+                on_layer_done("proj")
+    elif wide:
         param_grads_async("proj", g, x_in, gs, xs, side=tail[0])
     else:
         param_grads_async("proj", g, x_in, side=tail[0], narrow="proj" if narrow_ok(ws[0], True) else None)
@@ -554,8 +651,9 @@ def noised_input(diffusion, x, t, noise, uniforms, seed, step_counter=None):
     return x_in, idx0, idxt
 
 
-def _noised_categories(diffusion, x, x_in, t, uniforms, seed, step_counter):
-    """Categorical half of the forward noising (q_sample of :650-652) into x_in[:, n_num:]; returns (idx0, idxt)."""
+def _noised_categories(diffusion, x, x_in, t, uniforms, seed, step_counter, dense=True):
+    """Categorical half of the forward noising (q_sample of :650-652) into x_in[:, n_num:] (`dense`; otherwise only the
+    noised class indices are produced); returns (idx0, idxt)."""
     if not diffusion.has_cat:
         return None, None
     B = x.shape[0]
@@ -565,7 +663,7 @@ def _noised_categories(diffusion, x, x_in, t, uniforms, seed, step_counter):
     m, sk = diffusion._m, diffusion._sum_k
     idx0 = x[:, n:].to(torch.int32).contiguous()           # `x_cat.long()` of :650
     idxt = torch.empty_like(idx0)
-    xin_cat = x_in[:, n:]
+    xin_cat = x_in[:, n:] if dense else None
     check(lib().clava_multinomial_step_counter_f32(ctypes.byref(sched), c_int(2), c_int(B), c_int(m), c_int(sk),
                                                    ptr(diffusion._offsets_i32), ptr(diffusion._log_k), None, c_int(0), ptr(idx0),
                                                    ptr(idxt), ptr(uniforms), c_int(sk), ptr(xin_cat), c_int(D), None, c_int(0),
@@ -575,15 +673,16 @@ def _noised_categories(diffusion, x, x_in, t, uniforms, seed, step_counter):
     return idx0, idxt
 
 
-def draw_noised_input(diffusion, x, seed, step_counter):
+def draw_noised_input(diffusion, x, seed, step_counter, dense=True):
     """`draw` + `noised_input` with the draws made on the device (clava_train_draw_qsample_f32): timesteps, Gaussian
     noise and the numeric q-sample in one launch, keyed by (seed, *step_counter).  This is the captured step's form: it
     keeps torch's generator (two fill kernels before every replay, two draw kernels in it) out of the graph.  Returns
-    (t, noise, x_in, idx0, idxt)."""
+    (t, noise, x_in, idx0, idxt).  `dense=False`: x_in holds the numeric columns only and the log-one-hot image of the
+    noised categories is not written (the first layer runs in gather form from idxt)."""
     dev = x.device
     B = x.shape[0]
     n = diffusion.num_numerical_features
-    D = n + diffusion._sum_k
+    D = n + (diffusion._sum_k if dense else 0)
     x_in = torch.empty((B, D), device=dev, dtype=torch.float32)
     t = torch.empty(B, device=dev, dtype=torch.int64)
     noise = torch.empty((B, n), device=dev, dtype=torch.float32) if n > 0 else None
@@ -592,7 +691,7 @@ def draw_noised_input(diffusion, x, seed, step_counter):
     check(lib().clava_train_draw_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(xf), c_ll(xf.stride(0)), _lib.c_u64(seed),
                                              ctypes.c_uint(0), ptr(step_counter), ptr(t), ptr(noise), ptr(x_in), c_int(D),
                                              stream_ptr()), "clava_train_draw_qsample_f32")
-    idx0, idxt = _noised_categories(diffusion, x, x_in, t, None, seed, step_counter)
+    idx0, idxt = _noised_categories(diffusion, x, x_in, t, None, seed, step_counter, dense=dense)
     return t, noise, x_in, idx0, idxt
 
 

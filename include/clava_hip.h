@@ -386,7 +386,8 @@ int clava_silu_backward_f32(const float* z, const float* da, float* dz, long lon
  * emb = a1 W2^T + b2 (time_embed, modules.py:445-449, 452), h = x_in Wp^T + bp + emb (modules.py:459).  te, z1, a1
  * ([B, dim_t] each) are stored for the backward; h goes to `h` (float32 [B, dim_t], may be NULL) and / or to `h_split`
  * (split rows with `shift`, `pitch` bytes per row, may be NULL; *overflow as in clava_split_pack_f32).  dim_t must be 128
- * (every config's value); other widths use the separate kernels. */
+ * (every config's value); other widths use the separate kernels.  d_in = 0 leaves proj out: h = emb (tables whose first
+ * layer runs in gather form, clava_cat_input_f32, which adds its per-row embedding). */
 int clava_train_front_f32(const long long* t, int B, const float* freqs, int dim_t, const float* x_in, long long ldx, int d_in,
                           const float* w0, const float* b0, const float* w2, const float* b2, const float* wp, const float* bp,
                           float* te, float* z1, float* a1, float* h, void* h_split, long long pitch, int shift, int* overflow,
@@ -427,6 +428,27 @@ int clava_narrow_wgrad_f32(const float* A, long long lda, int D, const float* Bm
  * device step word `word`; the kernel reads them over the bus, so no host-synchronous copy separates two replays.  The
  * caller must not refill a buffer before the replay that reads it has finished (an event two steps back). */
 int clava_stage_fetch_f32(const float* host0, const float* host1, const unsigned* word, float* dst, long long n, void* stream);
+
+/* ---- first layer of a table with categorical columns in TRAINING, without the [B, sum K] log-one-hot image -------------
+ * clava_cat_input_f32: h = W_num x_num + (b + L S) + emb - L sum_f W[:, n_num + off_f + idx_f] (csrc/cat_input.hip; proj of
+ *   tab_ddpm/modules.py:459 on the input `index_to_log_onehot` builds, utils.py:127-134), from the TRANSPOSED weight
+ *   (num_wt [n_num][d1], cat_wt [sum K][d1]) and cat_bias = b + L * row sums of the categorical columns; emb is one
+ *   broadcast row (ld_emb = 0) or a row per batch row; output as split rows and optionally float32.  d1 % 128 == 0.
+ * clava_cat_wgrad_f32: the categorical columns of that layer's weight gradient per batch range,
+ *   dw_slabs[s][c][col0 + off_f + k] = L * (sum_b g[b][c] - sum_{b: idx[b][f] = k} g[b][c]) (csrc/cat_wgrad.hip; weight half
+ *   of loss.backward(), scripts/train.py:37), no atomics; g_colsum_slabs[s * slab_stride + c] = sum_b g[b][c] over batch range s (the
+ *   layer's bias-gradient slabs, computed first on the same stream).  wg_feature / wg_k0 (DEVICE arrays of n_workgroups ints) assign a
+ *   (feature, first class) to every workgroup: clava_cat_wgrad_workgroups counts them from the HOST offsets,
+ *   clava_cat_wgrad_plan fills host arrays the caller uploads once per table.  d1 must be 128. */
+int clava_cat_input_f32(const float* xnum, int ld_x, const int* idx, int B, int n_num, int m, int d1, const int* offsets,
+                        const float* num_wt, const float* cat_wt, const float* cat_bias, const float* emb, long long ld_emb,
+                        float log_tiny, int act, void* out_split, long long pitch, int shift, float* out_f32, long long ld_f32,
+                        int* overflow, void* stream);
+int clava_cat_wgrad_workgroups(const int* offsets_host, int m);
+int clava_cat_wgrad_plan(const int* offsets_host, int m, int* wg_feature_host, int* wg_k0_host);
+int clava_cat_wgrad_f32(const float* g, long long ldg, const float* g_colsum_slabs, int B, int d1, const int* idx, int m,
+                        const int* offsets, const int* wg_feature, const int* wg_k0, int n_workgroups, int splits, float log_tiny,
+                        float* dw_slabs, long long ldw, int col0, long long slab_stride, void* stream);
 
 /* The same update with the step-dependent scalars read from device memory, for a step captured in a hipGraph (kernel
  * arguments are frozen at capture): clava_adamw_hyper_f32 fills hyper8[0..7] on the HOST with exactly the values

@@ -283,7 +283,7 @@ def test_scale_sweep_training_step_vs_oracle():
     check("f32", lm, lg, slabs, saved32[4][1:-1])
     # ---- split-f16 step with wide end layers and split weight gradients, scales fixed by the float32 step above
     st = tr.SplitTrainState()
-    st.calibrate(net.stack()[0], saved32[4], gs, x_in=x_in, d_out=d_out)
+    st.calibrate(net.stack()[0], saved32[4], gs, x_in=x_in, d_out=d_out, n_num=n_num)
     assert D >= tr.WIDE_END_LAYERS and tr.wgrad_split_ok(B)
     out16, saved16 = tr.denoiser_forward_split(net, x_in, td, st)
     lm16, lg16, d_out16 = tr.loss_and_grad(d, out16, nd, idx0, idxt, td)
@@ -294,6 +294,23 @@ def test_scale_sweep_training_step_vs_oracle():
     acts16 = [ops.split_unpack(hs) for hs in saved16[5][1:]]
     check("f16x3", lm16, lg16, slabs16, acts16)
     assert relerr(out16, out32) < 1e-5
+    # ---- the same step with proj in GATHER form (what the captured step of a wide table runs): the first layer from the
+    # numeric columns and the noised class indices (csrc/cat_input.hip), its weight gradient from class-wise row sums
+    # (csrc/cat_wgrad.hip) and the numeric block; the [B, sum K] log-one-hot image is not an input
+    assert st.gather_ok(d, net, B)
+    x_num = x_in[:, :n_num].contiguous()
+    st.start_pack(net, D, gather_n_num=n_num)
+    outg, savedg = tr.denoiser_forward_split(net, x_num, td, st, cat=(idxt, d))
+    lmg, lgg, d_outg = tr.loss_and_grad(d, outg, nd, idx0, idxt, td)
+    slabsg = torch.full((tr.GRAD_SPLITS, layout.total), float("nan"), device=DEV)
+    tr.denoiser_backward_split(net, savedg, d_outg, layout, slabsg, st)
+    torch.cuda.synchronize()
+    assert int(st.flag.item()) == 0 and savedg[6] is None and savedg[7] is not None
+    for n in layout.names:                                                      # every slab of every parameter was written
+        assert all(bool(torch.isfinite(layout.view(slabsg[s_], n)).all()) for s_ in range(tr.GRAD_SPLITS)), n
+    check("gather", lmg, lgg, slabsg, [ops.split_unpack(hs) for hs in savedg[5][1:]])
+    assert relerr(outg, out32) < 1e-5 and relerr(ops.split_unpack(savedg[5][0]), ops.split_unpack(saved16[5][0])) < 2e-6
+    # (the two split paths' gradients are not compared with each other: their ReLU patterns differ in a few units, see above)
 
 
 def test_fused_guided_sample_honours_model_kwargs_labels():
