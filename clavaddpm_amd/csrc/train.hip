@@ -246,13 +246,25 @@ __global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
         b.lca_p = a.s.log_cumprod_alpha[tp];
         b.uni_p = a.s.log_1_min_cumprod_alpha[tp] - logk;
         const float la_t = a.s.log_alpha[b.t], uni_t = a.s.log_1_min_alpha[b.t] - logk;
-        b.q1_hot = log_add_exp_acc(0.f + la_t, uni_t);
-        b.q1_cold = log_add_exp_acc(LOG_TINY + la_t, uni_t);
-        b.evt_hot = b.ev(0.f);
-        b.evt_cold = b.ev(LOG_TINY);
-        const float lq_hot = log_add_exp_acc(0.f + lca_T, l1mca_T - logk), lq_cold = log_add_exp_acc(LOG_TINY + lca_T, l1mca_T - logk);
-        b.klp_hot = exp_nonpos(lq_hot) * (lq_hot + logk);
-        b.klp_cold = exp_nonpos(lq_cold) * (lq_cold + logk);
+        // The block's six log-add-exps -- q1 (hot, cold), ev at the clean / any other class, the prior's lq (hot, cold) -- in
+        // ONE evaluation: lane j computes the j-th (the same function on the same arguments as six scalar calls: identical
+        // bits), then the results are read back by lane.  The per-block set-up was ~40 % of the kernel's instructions at the
+        // scale-sweep shape, where the kernel is instruction bound on blocks of a few classes.
+        {
+            const float hot_cold = (lane & 1) ? LOG_TINY : 0.f;
+            const int which = lane >> 1;
+            const float x = hot_cold + (which == 0 ? la_t : which == 1 ? b.lca_p : lca_T);
+            const float y = which == 0 ? uni_t : which == 1 ? b.uni_p : l1mca_T - logk;
+            const float r = log_add_exp_acc(x, y);
+            const float kl = exp_nonpos(r) * (r + logk);
+            auto rl = [](float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
+            b.q1_hot = rl(r, 0);
+            b.q1_cold = rl(r, 1);
+            b.evt_hot = b.t == 0 ? 0.f : rl(r, 2);                 // ev is the identity at t = 0
+            b.evt_cold = b.t == 0 ? LOG_TINY : rl(r, 3);
+            b.klp_hot = rl(kl, 4);
+            b.klp_cold = rl(kl, 5);
+        }
         if (b.K <= 256) loss_block_cached<4>(a, b, lane, pair);
         else if (b.K <= 1024) loss_block_cached<16>(a, b, lane, pair);
         else loss_block_streamed(a, b, lane, pair);
