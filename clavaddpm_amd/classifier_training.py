@@ -203,6 +203,7 @@ class ClassifierTrainer:
         self.opt_step = 0
         self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)      # Dropout step counter, advanced on the device
+        self._host_step = 0           # host mirror of step_dev (its parity picks the captured step's pinned input buffer)
         self.history = []
         self._use_graph = os.environ.get("CLAVA_TRAIN_GRAPH", "1") != "0"
         self._graph = None
@@ -268,6 +269,17 @@ class ClassifierTrainer:
         if draws is not None:
             t = draws["t"].to(dev).long().contiguous()
             noise = draws["noise"].to(dev).float().contiguous()
+        elif _tr.DEVICE_DRAWS and getattr(self, "step_dev", None) is not None:
+            # t, noise and the q-sample in one launch from the counter-based generator, keyed like the Dropout masks by
+            # (seed, device step counter): torch's generator stays out of the captured step
+            t = torch.empty(B, device=dev, dtype=torch.int64)
+            noise = torch.empty((B, n), device=dev, dtype=torch.float32)
+            x_t = torch.empty((B, n), device=dev, dtype=torch.float32)
+            sched = d._c_schedule()
+            check(lib().clava_train_draw_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(x_num), c_ll(x_num.stride(0)),
+                                                     c_u64(self.seed ^ 0x5DEECE66D), ctypes.c_uint(0), ptr(self.step_dev), ptr(t), ptr(noise),
+                                                     ptr(x_t), c_int(n), stream_ptr()), "clava_train_draw_qsample_f32")
+            return x_t, t
         else:
             t = torch.randint(0, d.num_timesteps, (B,), device=dev).long()      # UniformSampler.sample (:676)
             noise = torch.randn((B, n), device=dev, dtype=torch.float32)
@@ -301,21 +313,75 @@ class ClassifierTrainer:
         self.step_dev += 1
         return loss, a1, a5, (saved, logits, rows, lse, acc1, acc5, x_t, t)
 
-    def _graphed(self, x_num, labels):
-        key = (tuple(x_num.shape),)
+    def _host_inputs(self, x, labels):
+        """The batch's numeric columns (float32) and labels without moving them to the device (the captured step fetches
+        them itself); labels on the host are range-checked like `_inputs` does."""
+        n = self.diffusion.num_numerical_features
+        if self.remove_first_col:
+            x = x[:, 1:]
+        x_num = x[:, :n]
+        if not labels.is_cuda and labels.numel():
+            lo, hi = int(labels.min()), int(labels.max())
+            n_out = _blocks(self.classifier)[2].out_features
+            if lo < 0 or hi >= n_out:
+                raise _lib.ClavaHipError(f"labels must lie in [0, {n_out}): got [{lo}, {hi}]")
+        return x_num, labels
+
+    def _adamw_hyper(self, n):
+        """The fused optimizer over the whole flat buffer, step scalars read from `_hyper_dev` (a captured step's form)."""
+        check(lib().clava_adamw_ema_hyper_f32(ptr(self.flat), None, ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.slabs),
+                                              c_int(_tr.GRAD_SPLITS), c_ll(self.layout.total), c_float(1.0), c_ll(n), ptr(self._hyper_dev),
+                                              ctypes.c_double(0.0), stream_ptr()), "clava_adamw_ema_hyper_f32")
+
+    def _graphed(self, x, labels):
+        """The whole step (input fetch, draws, forward, loss, backward, optimizer) as ONE hipGraph launch.  Inputs go through
+        two pinned host buffers used alternately (parity of the device step counter) and are fetched by the graph's first
+        node (`clava_stage_fetch_f32`): no host-synchronous copy sits between two replays (scripts/train.py has the
+        measurements).  Layout of a buffer, in 4-byte words: x_num [B, n] float32 | labels [B] int32 | 8 optimizer scalars."""
+        x_num, labels = self._host_inputs(x, labels)
+        B, n = x_num.shape
+        on_dev = x_num.is_cuda
+        key = (B, n, on_dev)
         gr = self._graph
         if gr is None or gr["key"] != key:
             if getattr(self, "_graph_warm", None) != key:          # first step of a shape runs eagerly (allocator warm-up)
                 self._graph_warm = key
                 return None
-            sx, sy = x_num.clone(), labels.clone()
+            dev = self.device
+            nw = B * n + B + 8
+            stage_dev = torch.zeros(nw, device=dev, dtype=torch.float32)
+            sx = stage_dev[:B * n].view(B, n)
+            sy32 = stage_dev[B * n:B * n + B].view(torch.int32)
+            self._hyper_dev = stage_dev[B * n + B:]
+            pins = [torch.zeros(nw, dtype=torch.float32).pin_memory() for _ in range(2)]
+            lo = B * n + B if on_dev else 0
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self._forward_backward(sx, sy, None)
-            gr = self._graph = {"key": key, "graph": graph, "x": sx, "y": sy, "out": out}
-        gr["x"].copy_(x_num)
-        gr["y"].copy_(labels)
+                check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self.step_dev), ptr(stage_dev[lo:]),
+                                                  c_ll(nw - lo), stream_ptr()), "clava_stage_fetch_f32")
+                out = self._forward_backward(sx, sy32.long(), None)
+                self._adamw_hyper(self.layout.total)
+            gr = self._graph = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
+                                "stage": stage_dev,
+                                "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * (B * n + B)) for p in pins]}
+        par = self._host_step & 1
+        if gr["ev"][par] is not None:
+            gr["ev"][par].synchronize()          # the replay two steps back, the last reader of this pinned buffer
+        check(lib().clava_adamw_hyper_f32(ctypes.c_double(self.lr), ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]),
+                                          ctypes.c_double(self.eps), ctypes.c_double(self.weight_decay), c_ll(self.opt_step + 1),
+                                          gr["hyper_host"][par]), "clava_adamw_hyper_f32")
+        if on_dev:
+            gr["x"].copy_(x_num)
+            gr["y32"].copy_(labels)
+        else:
+            pin = gr["pins"][par]
+            pin[:B * n].view(B, n).copy_(x_num)
+            pin[B * n:B * n + B].view(torch.int32).copy_(labels)
         gr["graph"].replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        gr["ev"][par] = ev
+        self._host_step += 1
         return gr["out"][:3]
 
     def step(self, x, labels, draws=None):
@@ -324,12 +390,16 @@ class ClassifierTrainer:
             raise _lib.ClavaHipError("ClassifierTrainer.step needs classifier.train()")
         if not self._flattened:
             self._flatten()
-        x_num, labels = self._inputs(x, labels, draws)
-        out = None
+        from . import split_nets
         if draws is None and self._use_graph and self.dist is None:
-            out = self._graphed(x_num, labels)
-        if out is None:
-            out = self._forward_backward(x_num, labels, draws)[:3]
+            out = self._graphed(x, labels)
+            if out is not None:                  # the optimizer ran inside the graph
+                self.opt_step += 1
+                split_nets.invalidate()          # parameters and BatchNorm statistics were rewritten through raw pointers
+                return out
+        x_num, labels = self._inputs(x, labels, draws)
+        out = self._forward_backward(x_num, labels, draws)[:3]
+        self._host_step += 1
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
@@ -342,7 +412,6 @@ class ClassifierTrainer:
                                         ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
                                         ctypes.c_double(self.weight_decay), c_ll(self.opt_step), ctypes.c_double(0.0), stream_ptr()),
               "clava_adamw_ema_f32")
-        from . import split_nets
         split_nets.invalidate()      # parameters and BatchNorm statistics were rewritten through raw pointers
         return out
 
