@@ -79,3 +79,103 @@ def test_narrow_wgrad_slabs_match_float64_in_both_layouts(B, D, J, splits):
         assert relerr(got, ref) < 2e-6
         assert relerr(slabs[:, D * J:D * J + D].double().sum(0), A.double().sum(0)) < 2e-6
         assert relerr(slabs[:, D * J + D:D * J + D + J].double().sum(0), Bm.double().sum(0)) < 2e-6
+
+
+def _cat_table(K, n_num, B, seed):
+    import numpy as np
+    from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+    K = np.array(K)
+    D = n_num + int(K.sum())
+    net = MLPDiffusion(D, 0, "none", {"d_layers": [64, 64], "dropout": 0.0}).to(DEV)
+    d = GaussianMultinomialDiffusion(K, n_num, net, num_timesteps=100, device=torch.device(DEV)).to(DEV)
+    g = _gen(seed)
+    idx = torch.stack([torch.randint(0, int(k), (B,), device=DEV, generator=g) for k in K], 1).to(torch.int32).contiguous()
+    return d, net, idx, D, g
+
+
+@pytest.mark.parametrize("K,n_num,B,splits", [([2, 7, 130, 300, 64], 3, 1000, 8), ([1000, 2], 0, 4096, 8), ([5], 100, 77, 3)])
+def test_cat_wgrad_matches_the_dense_product_with_the_log_one_hot_image(K, n_num, B, splits):
+    """csrc/cat_wgrad.hip: dW[:, n_num + off_f + k] = L * (sum_b g[b] - sum_{b: idx[b][f] = k} g[b]) against g^T @
+    index_to_log_onehot(idx) in float64 (tab_ddpm/utils.py:127-134; weight half of scripts/train.py:37); class ranges beyond
+    128 (several workgroups per feature), batch ranges with a short last one, columns outside the categorical block untouched."""
+    import ctypes
+    from clavaddpm_amd._lib import c_float, c_int, check, lib, ptr, stream_ptr
+    d, net, idx, D, g = _cat_table(K, n_num, B, sum(K) + B)
+    st = tr.SplitTrainState()
+    gp = st.gather_plan(d, DEV)
+    gr = torch.randn(B, 128, device=DEV, generator=g)
+    total = 128 * D + 128
+    slabs = torch.full((splits, total), 7.0, device=DEV)
+    rows_per = (B + splits - 1) // splits
+    bsl = slabs[:, 128 * D:]
+    for s_ in range(splits):
+        bsl[s_] = gr[s_ * rows_per:(s_ + 1) * rows_per].sum(0)
+    check(lib().clava_cat_wgrad_f32(ptr(gr), tr.c_ll(128), ptr(bsl), c_int(B), c_int(128), ptr(idx), c_int(gp["m"]), ptr(d._offsets_i32),
+                                    ptr(gp["wf"]), ptr(gp["wk"]), c_int(gp["nwg"]), c_int(splits), c_float(gp["log_tiny"]), ptr(slabs),
+                                    tr.c_ll(D), c_int(n_num), tr.c_ll(total), stream_ptr()), "clava_cat_wgrad_f32")
+    x = torch.full((B, sum(K)), gp["log_tiny"], device=DEV, dtype=torch.float64)
+    x.scatter_(1, idx.long() + d._offsets_i32.long()[:-1][None, :], 0.0)
+    ref = gr.double().T @ x
+    got = slabs[:, :128 * D].view(splits, 128, D)
+    assert relerr(got[:, :, n_num:].double().sum(0), ref) < 2e-6
+    assert bool((got[:, :, :n_num] == 7.0).all())                       # the numeric block belongs to another kernel
+
+
+@pytest.mark.parametrize("K,n_num,B", [([4, 9, 200], 5, 333), ([3], 0, 64)])
+def test_cat_input_with_per_row_embedding_matches_the_dense_first_layer(K, n_num, B):
+    """csrc/cat_input.hip in its training form: per-row time embedding, split rows AND float32 output, against proj on the
+    dense [B, n_num + sum K] input (tab_ddpm/modules.py:459) in float64."""
+    from clavaddpm_amd._lib import c_float, c_int, check, lib, ptr, stream_ptr
+    d, net, idx, D, g = _cat_table(K, n_num, B, 5 * B)
+    st = tr.SplitTrainState()
+    gp = st.gather_plan(d, DEV)
+    w = torch.randn(128, D, device=DEV, generator=g) / D ** 0.5
+    b = torch.randn(128, device=DEV, generator=g)
+    emb = torch.randn(B, 128, device=DEV, generator=g)
+    xn = torch.randn(B, max(n_num, 1), device=DEV, generator=g)[:, :n_num].contiguous()
+    st.gather_weights(w, b, n_num)
+    out = ops.split_empty(B, 128, 0, DEV)
+    flag = ops.overflow_flag(DEV)
+    h32 = torch.empty(B, 128, device=DEV)
+    check(lib().clava_cat_input_f32(ptr(xn) if n_num else None, c_int(max(n_num, 1)), ptr(idx), c_int(B), c_int(n_num), c_int(gp["m"]), c_int(128),
+                                    ptr(d._offsets_i32), ptr(st._wt0) if n_num else None, ptr(st._wt0[n_num:]), ptr(st._cat_bias), ptr(emb),
+                                    tr.c_ll(128), c_float(gp["log_tiny"]), c_int(0), ptr(out.buf), tr.c_ll(out.pitch), c_int(3), ptr(h32),
+                                    tr.c_ll(128), ptr(flag), stream_ptr()), "clava_cat_input_f32")
+    out.shift = 3
+    x = torch.full((B, sum(K)), gp["log_tiny"], device=DEV, dtype=torch.float64)
+    x.scatter_(1, idx.long() + d._offsets_i32.long()[:-1][None, :], 0.0)
+    ref = torch.cat([xn.double(), x], 1) @ w.double().T + b.double() + emb.double()
+    assert int(flag.item()) == 0
+    assert relerr(h32, ref) < 4e-6 and relerr(ops.split_unpack(out), ref) < 4e-6
+
+
+def test_optimizer_with_device_scalars_is_bit_equal_to_the_argument_form():
+    """clava_adamw_hyper_f32 + clava_adamw_ema_hyper_f32 (a captured step's optimizer) against clava_adamw_ema_f32 on the
+    same state: identical bits for parameters, moments and EMA."""
+    import ctypes
+    from clavaddpm_amd._lib import c_float, c_int, check, lib, ptr, stream_ptr
+    g = _gen(3)
+    n, S = 100003, 4
+    p0, m0 = torch.randn(n, device=DEV, generator=g), torch.randn(n, device=DEV, generator=g) * 1e-3
+    v0 = torch.rand(n, device=DEV, generator=g) * 1e-6
+    slabs = torch.randn(S, n, device=DEV, generator=g) * 1e-2
+    cd = ctypes.c_double
+    hp = dict(lr=3e-4, b1=0.9, b2=0.999, eps=1e-8, wd=1e-5, step=17, ema=0.999)
+    res = []
+    for form in ("args", "device"):
+        p, e, m, v = p0.clone(), p0.clone(), m0.clone(), v0.clone()
+        if form == "args":
+            check(lib().clava_adamw_ema_f32(ptr(p), ptr(e), ptr(m), ptr(v), ptr(slabs), c_int(S), tr.c_ll(n), c_float(1.0), tr.c_ll(n), cd(hp["lr"]),
+                                            cd(hp["b1"]), cd(hp["b2"]), cd(hp["eps"]), cd(hp["wd"]), tr.c_ll(hp["step"]), cd(hp["ema"]), stream_ptr()),
+                  "clava_adamw_ema_f32")
+        else:
+            host = (ctypes.c_float * 8)()
+            check(lib().clava_adamw_hyper_f32(cd(hp["lr"]), cd(hp["b1"]), cd(hp["b2"]), cd(hp["eps"]), cd(hp["wd"]), tr.c_ll(hp["step"]), host),
+                  "clava_adamw_hyper_f32")
+            hd = torch.tensor(list(host), device=DEV, dtype=torch.float32)
+            check(lib().clava_adamw_ema_hyper_f32(ptr(p), ptr(e), ptr(m), ptr(v), ptr(slabs), c_int(S), tr.c_ll(n), c_float(1.0), tr.c_ll(n),
+                                                  ptr(hd), cd(hp["ema"]), stream_ptr()), "clava_adamw_ema_hyper_f32")
+        res.append((p, e, m, v))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][0], p0)
