@@ -167,6 +167,50 @@ __global__ void __launch_bounds__(256) train_front_kernel(FrontArgs a) {
     if (ovf && a.overflow) *a.overflow = 1;
 }
 
+// Backward through time_embed[2] and the SiLU in one launch: d_z1 = SiLU'(z1) * (g W2), g = d loss / d emb [B, 128]
+// (the autograd backward of tab_ddpm/modules.py:445-449 between emb and z1).  Same tiling as the front: 16 rows per
+// workgroup, W2 staged TRANSPOSED in LDS ([input k][132]) so that thread k of a row contracts over the output index.
+struct TimeBwdArgs {
+    const float* g; long long ldg;
+    const float* w2;                  // [128 out][128 in]
+    const float* z1; float* dz1;      // [B, 128]
+    int B;
+};
+
+__global__ void __launch_bounds__(256) train_time_bwd_kernel(TimeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl[DT * LDW];
+    __shared__ __attribute__((aligned(16))) float act0[ROWS * LDW];
+    const int tid = threadIdx.x, c = tid & 127, half = tid >> 7;
+    const long long row0 = (long long)blockIdx.x * ROWS;
+    f4 pre[16];
+    fetch_w(pre, a.w2, DT, 0, DT, tid);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j, r = idx >> 7, k = idx & 127;
+        act0[r * LDW + k] = a.g[min(row0 + r, (long long)a.B - 1) * a.ldg + k];
+    }
+    // wl[k][o] = W2[o][k]: element e of pre[j] is W2[row = idx >> 5][4 (idx & 31) + e]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int idx = tid + 256 * j, o = idx >> 5, k = (idx & 31) << 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wl[(k + e) * LDW + o] = pre[j][e];
+    }
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    fma_rows(acc, act0, wl, c, half, DT / 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long row = row0 + 8 * half + i;
+        if (row >= a.B) continue;
+        const float v = a.z1[row * DT + c];
+        const float sg = 1.0f / (1.0f + expf(-v));
+        a.dz1[row * DT + c] = acc[i] * (sg * (1.0f + v * (1.0f - sg)));      // silu_bwd_kernel's formula (train.hip)
+    }
+}
+
 }  // namespace
 
 extern "C" int clava_train_front_f32(const long long* t, int B, const float* freqs, int dim_t, const float* x_in, long long ldx, int d_in,
@@ -193,5 +237,17 @@ extern "C" int clava_train_front_f32(const long long* t, int B, const float* fre
     ProfScope prof(PROF_MISC, flops, 4.0 * B * (4.0 * DT + d_in), (hipStream_t)stream);
     hipLaunchKernelGGL(train_front_kernel, dim3((B + ROWS - 1) / ROWS), dim3(256), 0, (hipStream_t)stream, a);
     CLAVA_CHECK_LAUNCH("clava_train_front_f32");
+    return CLAVA_OK;
+}
+
+extern "C" int clava_train_time_bwd_f32(const float* g, long long ldg, int B, int dim_t, const float* w2, const float* z1, float* d_z1,
+                                        void* stream) {
+    CLAVA_CHECK_ARG(dim_t == DT, "train_time_bwd: dim_t %d not supported (built for 128)", dim_t);
+    CLAVA_CHECK_ARG(g && w2 && z1 && d_z1 && B > 0 && ldg >= DT, "train_time_bwd: bad arguments");
+    TimeBwdArgs a;
+    a.g = g; a.ldg = ldg; a.w2 = w2; a.z1 = z1; a.dz1 = d_z1; a.B = B;
+    ProfScope prof(PROF_MISC, 2.0 * B * DT * DT, 4.0 * B * 3.0 * DT, (hipStream_t)stream);
+    hipLaunchKernelGGL(train_time_bwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(256), 0, (hipStream_t)stream, a);
+    CLAVA_CHECK_LAUNCH("clava_train_time_bwd_f32");
     return CLAVA_OK;
 }

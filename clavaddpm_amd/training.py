@@ -589,8 +589,13 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     else:
         param_grads_async("proj", g, x_in, side=tail[0], narrow="proj" if narrow_ok(ws[0], True) else None)
     param_grads_async("time_embed.2", g, a1, side=tail[1])
-    d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
-    d_z1 = _silu_backward(z1, d_a1)
+    if FRONT_FUSED and net.dim_t == 128 and g.stride(1) == 1:
+        d_z1 = torch.empty_like(z1)               # input gradient of time_embed[2] and SiLU' in one launch
+        check(lib().clava_train_time_bwd_f32(ptr(g), c_ll(g.stride(0)), c_int(M), c_int(128), ptr(net.time_embed[2].weight.detach()),
+                                             ptr(z1), ptr(d_z1), stream_ptr()), "clava_train_time_bwd_f32")
+    else:
+        d_a1 = ops.linear_dgrad(g, net.time_embed[2].weight.detach())
+        d_z1 = _silu_backward(z1, d_a1)
     if TAIL_BRANCHES:
         keep.append((d_z1, te))
         param_grads("time_embed.0", d_z1, te)

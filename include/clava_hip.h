@@ -401,6 +401,11 @@ int clava_adamw_ema_f32(float* param, float* ema, float* exp_avg, float* exp_avg
                         long long slab_stride, float grad_scale, long long n, double lr, double beta1, double beta2,
                         double eps, double weight_decay, long long step, double ema_rate, void* stream);
 
+/* d_z1 = SiLU'(z1) * (g W2): the backward from the time embedding (g = d loss / d emb, [B, dim_t]) through time_embed[2] and the
+ * SiLU in one launch (autograd of tab_ddpm/modules.py:445-449); W2 is time_embed[2].weight [dim_t, dim_t]; dim_t must be 128. */
+int clava_train_time_bwd_f32(const float* g, long long ldg, int B, int dim_t, const float* w2, const float* z1, float* d_z1,
+                             void* stream);
+
 /* ---- narrow end layers of the denoiser in training (csrc/narrow.hip): D <= 16 columns on one side -----------------
  * Memory-bound replacements of the tiled products for the head Linear(K, D) and proj Linear(D, J) of numeric tables.
  * clava_narrow_head_f32: out[b][d] = bias[d] + sum_k h[b][k] W[d][k] (tab_ddpm/modules.py:460); K % 4 == 0, rows of h

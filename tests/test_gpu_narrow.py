@@ -179,3 +179,20 @@ def test_optimizer_with_device_scalars_is_bit_equal_to_the_argument_form():
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert not torch.equal(res[0][0], p0)
+
+
+@pytest.mark.parametrize("B", [4096, 37])
+def test_time_embedding_backward_kernel_matches_float64(B):
+    """clava_train_time_bwd_f32: d_z1 = SiLU'(z1) * (g @ W2) against float64 (autograd of tab_ddpm/modules.py:445-449)."""
+    from clavaddpm_amd._lib import c_int, check, lib, ptr, stream_ptr
+    g = _gen(B)
+    gr = torch.randn(B, 130, device=DEV, generator=g)[:, :128] * 1e-3
+    w2 = torch.randn(128, 128, device=DEV, generator=g) / 11
+    z1 = torch.randn(B, 128, device=DEV, generator=g) * 3
+    dz = torch.empty_like(z1)
+    check(lib().clava_train_time_bwd_f32(ptr(gr), tr.c_ll(gr.stride(0)), c_int(B), c_int(128), ptr(w2), ptr(z1), ptr(dz), stream_ptr()),
+          "clava_train_time_bwd_f32")
+    zd = z1.double()
+    sg = torch.sigmoid(zd)
+    ref = (gr.double() @ w2.double()) * (sg * (1 + zd * (1 - sg)))
+    assert relerr(dz, ref) < 2e-6
