@@ -166,14 +166,15 @@ class Trainer:
         # CLAVA_TRAIN_GRAPH_DP=1 (the collective is outside the captured region either way)
         use_graph = self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP") == "1")
         if (st is not None and not st.due() and draws is None and use_graph):
-            # a host batch is copied straight into the graph's input buffer (one pageable copy, no device-to-device hop).
-            # A ring of pinned buffers with asynchronous copies was measured and is SLOWER here (1.03 vs 0.765 ms/step):
-            # the copy engine's cross-queue hand-over costs more than the 18 us the host-side wait does
             done = self._graphed_split_step(x, st)
             if done is not None and done[2]:                  # the optimizer ran inside the graph
                 return self._loss_pair(done[0], done[1])
             if done is not None:
                 return self._optimizer_step(x, done[0], done[1])
+        if st is not None and st.due() and draws is None and use_graph and st.shift_h is not None:
+            done = self._graphed_calibration_step(x, st)
+            if done is not None:
+                return self._loss_pair(done[0], done[1])
         x = x.to(self.device)
         if st is not None and st.due() and getattr(self, "_graph", None) is not None:
             # a calibration step synchronises anyway: check the host's mirror of the step word against the device
@@ -202,16 +203,71 @@ class Trainer:
                                         on_layer_done=self._dp_layer_done if overlap else None)
         return self._optimizer_step(x, loss_multi, loss_gauss)
 
+    # ---- captured steps ---------------------------------------------------------------------------------------------------
+    def _staging(self, x):
+        """Input staging shared by the captured steps of one batch shape.  The step's inputs -- the batch (as float32) and
+        the optimizer's eight step scalars -- live in one device buffer.  The host writes them into one of two PINNED
+        buffers, alternating with the parity of the step word, and a graph's first node fetches from the one its parity
+        names (clava_stage_fetch_f32).  No host-synchronous copy sits between two replays: the host prepares step i+1
+        while step i runs (a pageable `copy_` waited for step i to finish and left the GPU idle ~40 us per step;
+        asynchronous copies from pinned memory through the copy engine were slower still, 1.03 vs 0.77 ms/step).  A batch
+        already on the device is copied device-to-device in stream order and only the scalars go through the pinned
+        buffers."""
+        key = (tuple(x.shape), x.is_cuda)
+        sg = getattr(self, "_stage", None)
+        if sg is None or sg["key"] != key:
+            B, Dx = x.shape
+            n_x = B * Dx
+            stage_dev = torch.zeros(n_x + 8, device=self.flat.device, dtype=torch.float32)
+            pins = [torch.zeros(n_x + 8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            sg = self._stage = {"key": key, "dev": stage_dev, "x": stage_dev[:n_x].view(B, Dx), "pins": pins, "ev": [None, None],
+                                "lo": n_x if x.is_cuda else 0, "n": n_x + 8,
+                                "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * n_x) for p in pins]}
+            sg["x"].copy_(x)
+            self._hyper_dev = stage_dev[n_x:]
+            self._graph = self._cal_graph = None          # graphs captured on another staging buffer are stale
+        return sg
+
+    def _fetch_node(self, sg):
+        """The captured step's first node: stage buffer <- the pinned buffer of the step word's parity."""
+        lo = sg["lo"]
+        check(lib().clava_stage_fetch_f32(ptr(sg["pins"][0][lo:]), ptr(sg["pins"][1][lo:]), ptr(self._step_word), ptr(sg["dev"][lo:]),
+                                          c_ll(sg["n"] - lo), stream_ptr()), "clava_stage_fetch_f32")
+
+    def _replay(self, sg, graph, x, opt):
+        """Fills this step's pinned buffer (batch + optimizer scalars), replays `graph`, advances the host's step mirror."""
+        par = self._host_word & 1
+        if sg["ev"][par] is not None:
+            sg["ev"][par].synchronize()          # the replay two steps back, the last reader of this pinned buffer
+        if opt:
+            check(lib().clava_adamw_hyper_f32(ctypes.c_double(self.lr), ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]),
+                                              ctypes.c_double(self.eps), ctypes.c_double(self.weight_decay), c_ll(self.opt_step + 1),
+                                              sg["hyper_host"][par]), "clava_adamw_hyper_f32")
+        if x.is_cuda:
+            sg["x"].copy_(x)
+        else:
+            sg["pins"][par][:x.numel()].view(x.shape).copy_(x)
+        graph.replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        sg["ev"][par] = ev
+        self._host_word += 1
+        if opt:
+            self.opt_step += 1
+            from .. import split_nets
+            split_nets.invalidate()      # the optimizer kernels rewrote the parameters through raw pointers
+
     def _graphed_split_step(self, x, st):
-        """The split-f16 step (draws, q-sample, forward, losses, backward into the gradient slabs) as ONE hipGraph launch.
-        The step is ~100 small host calls; at 1.0 ms of GPU work per step the Python side is the bottleneck otherwise.
-        The graph is re-captured whenever the plane scales change (every calibration) or the batch shape does; the
-        first split step after a calibration runs eagerly and allocates the buffers the capture then reuses.  Not used
-        with injected draws or CLAVA_TRAIN_GRAPH=0.  The captured step draws t, the Gaussian noise and the categorical
-        uniforms from the library's counter-based generator, keyed by a seed baked in at capture and a device step word
-        that every replay advances (clava_train_draw_qsample_f32, clava_multinomial_step_counter_f32); eager steps draw
-        from torch's generator as the reference does.  CLAVA_TRAIN_DRAWS=torch keeps torch's generator in the graph."""
-        key = (tuple(x.shape), st.generation, x.is_cuda)
+        """The split-f16 step (input fetch, draws, q-sample, forward, losses, backward into the gradient slabs, optimizer) as
+        ONE hipGraph launch.  The step is ~100 small host calls; at 0.65 ms of GPU work per step the Python side is the
+        bottleneck otherwise.  The graph is re-captured when a calibration moved a plane scale or the batch shape changed;
+        the first split step after that runs eagerly and allocates the buffers the capture then reuses.  Not used with
+        injected draws or CLAVA_TRAIN_GRAPH=0.  The captured step draws t, the Gaussian noise and the categorical uniforms
+        from the library's counter-based generator, keyed by the Trainer's seed and a device step word that every step
+        advances (clava_train_draw_qsample_f32, clava_multinomial_step_counter_f32), like the eager steps;
+        CLAVA_TRAIN_DRAWS=torch keeps torch's generator in the graph.  Returns (loss_multi, loss_gauss, optimizer ran)."""
+        sg = self._staging(x)
+        key = (sg["key"], st.generation)
         gr = getattr(self, "_graph", None)
         if gr is None or gr["key"] != key:
             if getattr(self, "_graph_warm", None) != key:
@@ -220,24 +276,10 @@ class Trainer:
             d = self.diffusion
             net = d._denoise_fn
             dev = self.flat.device
-            # The step's inputs -- the batch (as float32) and the optimizer's eight step scalars -- live in one device
-            # buffer.  The host writes them into one of two PINNED buffers, alternating with the parity of the step word,
-            # and the graph's first node fetches from the one its parity names (clava_stage_fetch_f32).  No
-            # host-synchronous copy sits between two replays: the host prepares step i+1 while step i runs (a pageable
-            # `copy_` waited for step i to finish and left the GPU idle ~40 us per step; asynchronous copies from pinned
-            # memory through the copy engine were slower still, 1.03 vs 0.77 ms/step).  A batch already on the device is
-            # copied device-to-device in stream order and only the scalars go through the pinned buffers.
-            B, Dx = x.shape
-            n_x = B * Dx
-            stage_dev = torch.zeros(n_x + 8, device=dev, dtype=torch.float32)
-            static_x = stage_dev[:n_x].view(B, Dx)
-            static_x.copy_(x)
-            self._hyper_dev = stage_dev[n_x:]
-            pins = [torch.zeros(n_x + 8, dtype=torch.float32).pin_memory() for _ in range(2)]
-            lo = n_x if x.is_cuda else 0                           # first element the fetch node brings in
+            B = x.shape[0]
+            static_x = sg["x"]
             # optimizer inside the graph (single process only: data parallel puts an all-reduce between the two halves)
             graph_opt = self.dist is None and os.environ.get("CLAVA_TRAIN_GRAPH_OPT", "1") != "0"
-            graph = torch.cuda.CUDAGraph()
             # wide tables with categorical columns: proj and its weight gradient from (numeric columns, class indices),
             # the [B, sum K] log-one-hot image is never built (csrc/cat_input.hip, csrc/cat_wgrad.hip)
             gather = st.gather_ok(d, net, B)
@@ -245,11 +287,11 @@ class Trainer:
                 st.gather_plan(d, dev)
                 st.gather_weights(net.stack()[0][0].detach(), net.stack()[1][0].detach(), d.num_numerical_features)   # allocates
                 st.pack_weights(net.stack()[0], True, dev, gather=True)      # builds the packing plan (an upload: not capturable)
+            graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 st.start_pack(net, d.num_numerical_features + d._sum_k,      # denoiser input width
                               gather_n_num=d.num_numerical_features if gather else None)
-                check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self._step_word), ptr(stage_dev[lo:]),
-                                                  c_ll(n_x + 8 - lo), stream_ptr()), "clava_stage_fetch_f32")
+                self._fetch_node(sg)
                 if _tr.DEVICE_DRAWS:
                     # every draw of the step from the counter-based generator, keyed by (the Trainer's seed, device step word
                     # advanced once per step): the same draws as the eager step, and torch's generator stays out of the graph
@@ -283,30 +325,43 @@ class Trainer:
                 if graph_opt:
                     self._adamw_range(cut, self.layout.total)
             gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise),
-                                "stage_dev": stage_dev, "pins": pins, "opt": graph_opt, "ev": [None, None],
-                                "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * n_x) for p in pins]}
-        par = self._host_word & 1
-        if gr["ev"][par] is not None:
-            gr["ev"][par].synchronize()          # the replay two steps back, the last reader of this pinned buffer
-        if gr["opt"]:
-            check(lib().clava_adamw_hyper_f32(ctypes.c_double(self.lr), ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]),
-                                              ctypes.c_double(self.eps), ctypes.c_double(self.weight_decay), c_ll(self.opt_step + 1),
-                                              gr["hyper_host"][par]), "clava_adamw_hyper_f32")
-        if x.is_cuda:
-            gr["x"].copy_(x)
-        else:
-            gr["pins"][par][:x.numel()].view(x.shape).copy_(x)
-        gr["graph"].replay()
-        ev = torch.cuda.Event()
-        ev.record()
-        gr["ev"][par] = ev
-        self._host_word += 1
+                                "opt": graph_opt}
+        self._replay(sg, gr["graph"], x, gr["opt"])
         st.steps_since += 1
-        if gr["opt"]:
-            self.opt_step += 1
-            from .. import split_nets
-            split_nets.invalidate()      # the optimizer kernels rewrote the parameters through raw pointers
         return gr["lm"], gr["lg"], gr["opt"]
+
+    def _graphed_calibration_step(self, x, st):
+        """The float32 step that re-fixes the plane scales every `period` steps, as a second captured graph (eager it is ~90
+        launches and ~35 torch reductions, ~7 ms per window against 1.5 ms of GPU work): fetch, draws, float32 forward /
+        loss / backward, the largest magnitudes of every tensor as one device vector, optimizer.  The window's one host
+        synchronisation -- overflow flag and that vector -- follows the replay.  The first calibrations of a shape run
+        eagerly.  Returns (loss_multi, loss_gauss) or None."""
+        if self.dist is not None or os.environ.get("CLAVA_TRAIN_GRAPH_OPT", "1") == "0" or not _tr.DEVICE_DRAWS or st.flag is None:
+            return None
+        sg = self._staging(x)
+        gr = getattr(self, "_cal_graph", None)
+        d = self.diffusion
+        net = d._denoise_fn
+        if gr is None or gr["key"] != sg["key"]:
+            if getattr(self, "_cal_warm", None) != sg["key"]:
+                self._cal_warm = sg["key"]
+                return None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._fetch_node(sg)
+                t, noise, x_in, idx0, idxt = _tr.draw_noised_input(d, sg["x"], self._draw_seed, self._step_word)
+                self._step_word.add_(1)
+                model_out, saved = _tr.denoiser_forward(net, x_in, t)
+                lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+                gs = [None] * len(saved[4])
+                _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs, collect=gs)
+                stats = st.calibration_stats(net.stack()[0], saved[4], gs, x_in, d_out, d.num_numerical_features)
+                self._adamw_range(0, self.layout.total)
+            gr = self._cal_graph = {"key": sg["key"], "graph": graph, "lm": lm, "lg": lg, "stats": stats, "n": len(saved[4]),
+                                    "keep": (saved, d_out, x_in, t, noise, gs)}
+        self._replay(sg, gr["graph"], x, True)
+        st.calibrate_from(gr["stats"], gr["n"], bool(d.num_numerical_features))
+        return gr["lm"], gr["lg"]
 
     def _optimizer_step(self, x, loss_multi, loss_gauss):
         self.opt_step += 1

@@ -296,24 +296,32 @@ class SplitTrainState:
         """ws[l], hs[l] (layer outputs), gs[l] (gradient w.r.t. layer l's pre-activation, l <= n-2) from a float32 step;
         x_in / d_out (denoiser input, loss gradient) fix the scales of the wide end layers' operands; `n_num` (numeric
         columns at the front of x_in) fixes the scale of the numeric block alone (gather form of the first layer)."""
-        from .split_nets import TARGET_LOG2, shift_for
+        self.calibrate_from(self.calibration_stats(ws, hs, gs, x_in, d_out, n_num), len(ws), x_in is not None and bool(n_num))
+
+    @staticmethod
+    def calibration_stats(ws, hs, gs, x_in=None, d_out=None, n_num=None):
+        """The largest magnitudes `calibrate_from` turns into scales, as one device tensor (capturable: no host access)."""
         n = len(ws)
+        zero = torch.zeros((), device=ws[0].device)
+        return torch.stack([w.detach().abs().max() for w in ws] + [h.abs().max() for h in hs] +
+                           [gs[l].abs().max() if gs[l] is not None else zero for l in range(n)] +
+                           [x_in.abs().max() if x_in is not None else zero, d_out.abs().max() if d_out is not None else zero,
+                            x_in[:, :n_num].abs().max() if x_in is not None and n_num else zero])
+
+    def calibrate_from(self, stats, n, has_xn):
+        """Reads the overflow flag and the statistics (the window's one host synchronisation) and fixes the scales."""
+        from .split_nets import TARGET_LOG2, shift_for
         if self.flag is None:
-            self.flag = torch.zeros(1, device=ws[0].device, dtype=torch.int32)
+            self.flag = torch.zeros(1, device=stats.device, dtype=torch.int32)
         elif int((self.flag_reduce(self.flag.clone()) if self.flag_reduce is not None else self.flag).item()) != 0:
             raise _lib.SplitOverflowError("split-f16 training: a tensor left the float16 range since the last calibration "
                                           "(magnitudes grew by more than 60x within %d steps)" % self.period)
-        zero = torch.zeros((), device=ws[0].device)
-        stats = torch.stack([w.detach().abs().max() for w in ws] + [h.abs().max() for h in hs] +
-                            [gs[l].abs().max() if gs[l] is not None else zero for l in range(n)] +
-                            [x_in.abs().max() if x_in is not None else zero, d_out.abs().max() if d_out is not None else zero,
-                             x_in[:, :n_num].abs().max() if x_in is not None and n_num else zero])
         v = stats.cpu().tolist()
         before = (getattr(self, "shift_x", None), getattr(self, "shift_d", None), getattr(self, "shift_xn", None), self.shift_w,
                   self.shift_h, self.shift_g)
         self.shift_x = shift_for(v[3 * n], TARGET_LOG2 + 1)      # the log-one-hot columns are exactly 0 / -69.08
         self.shift_d = shift_for(v[3 * n + 1], TARGET_LOG2)
-        self.shift_xn = shift_for(v[3 * n + 2], TARGET_LOG2) if (x_in is not None and n_num) else None
+        self.shift_xn = shift_for(v[3 * n + 2], TARGET_LOG2) if has_xn else None
         self.shift_w = [shift_for(x, 10) for x in v[:n]]
         self.shift_h = [shift_for(x, TARGET_LOG2) for x in v[n:2 * n]]
         self.shift_g = [shift_for(x, TARGET_LOG2) for x in v[2 * n:3 * n]]

@@ -333,3 +333,43 @@ def test_numeric_table_graph_replays_draw_fresh_timesteps_and_noise():
         assert float((ta != tb).float().mean()) > 0.95 and float((za != zb).float().mean()) > 0.99
     finally:
         split_nets.set_gemm_mode(prev)
+
+
+def test_captured_steps_follow_the_eager_trajectory():
+    """Graph replays (split-f16 step and the captured float32 calibration step, inputs through the pinned mailbox, optimizer
+    inside the graph) against the same Trainer run eagerly: the draws are keyed by (seed, step word), the kernels are the
+    same, so the losses of all 40 steps (a calibration every 6) agree to 1e-5 and the final weights to 2e-5."""
+    import copy
+    from clavaddpm_amd import split_nets
+    prev = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode("f16x3")
+    try:
+        torch.manual_seed(3)
+        B = 512
+        net0 = MLPDiffusion(2, 0, "none", {"d_layers": [128, 256, 128], "dropout": 0.0}).to(DEV).train()
+        g = torch.Generator().manual_seed(4)
+        batches = [torch.randn(B, 2, generator=g) for _ in range(40)]
+        y = {"y": torch.zeros(B, dtype=torch.long)}
+        finals, cal = [], []
+        for use_graph in (True, False):
+            net = copy.deepcopy(net0)
+            d = GaussianMultinomialDiffusion(np.array([0]), 2, net, num_timesteps=1000, device=torch.device(DEV)).to(DEV).train()
+            torch.manual_seed(5)                        # the Trainer takes its draw seed from torch's CPU generator
+            tr = Trainer(d, None, lr=1e-3, weight_decay=1e-5, steps=10 ** 6, device=torch.device(DEV))
+            tr._use_graph = use_graph
+            tr.split_period = 6
+            losses = []
+            for x in batches:
+                lm, lg = tr._run_step(x, y)
+                losses.append(lg.clone())       # a replayed step returns the graph's static output tensor
+            finals.append((tr.flat.clone(), tr.ema_flat.clone(), torch.stack(losses).cpu()))
+            cal.append(getattr(tr, "_cal_graph", None) is not None and getattr(tr, "_graph", None) is not None)
+            assert tr.opt_step == 40 and int(tr._step_word.item()) == 40 == tr._host_word
+        assert cal == [True, False]                     # both captured graphs were in use in the first run, none in the second
+        (wa, ea, la), (wb, eb, lb) = finals
+        assert float((la - lb).abs().max()) < 1e-5 * float(lb.abs().max())
+        # (not bit-equal: Adam turns rounding-level gradient differences of the two launch orders into O(lr * 1e-3) steps)
+        assert float((wa - wb).abs().max()) < 2e-5 * float(wb.abs().max())
+        assert float((ea - eb).abs().max()) < 2e-5 * float(eb.abs().max())
+    finally:
+        split_nets.set_gemm_mode(prev)
