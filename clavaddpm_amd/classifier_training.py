@@ -342,11 +342,15 @@ class ClassifierTrainer:
         B, n = x_num.shape
         on_dev = x_num.is_cuda
         key = (B, n, on_dev)
-        gr = self._graph
-        if gr is None or gr["key"] != key:
-            if getattr(self, "_graph_warm", None) != key:          # first step of a shape runs eagerly (allocator warm-up)
-                self._graph_warm = key
+        graphs = self.__dict__.setdefault("_graphs", {})          # one captured step per batch shape (an epoch's short last batch)
+        gr = graphs.get(key)
+        if gr is None:
+            warm = self.__dict__.setdefault("_graph_warm", set())
+            if key not in warm:                                    # first step of a shape runs eagerly (allocator warm-up)
+                warm.add(key)
                 return None
+            if len(graphs) >= 4:
+                graphs.pop(next(iter(graphs)))
             dev = self.device
             nw = B * n + B + 8
             stage_dev = torch.zeros(nw, device=dev, dtype=torch.float32)
@@ -361,9 +365,10 @@ class ClassifierTrainer:
                                                   c_ll(nw - lo), stream_ptr()), "clava_stage_fetch_f32")
                 out = self._forward_backward(sx, sy32.long(), None)
                 self._adamw_hyper(self.layout.total)
-            gr = self._graph = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
-                                "stage": stage_dev,
+            gr = graphs[key] = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
+                                "stage": stage_dev, "hyper": self._hyper_dev,
                                 "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * (B * n + B)) for p in pins]}
+        self._graph = gr
         par = self._host_step & 1
         if gr["ev"][par] is not None:
             gr["ev"][par].synchronize()          # the replay two steps back, the last reader of this pinned buffer

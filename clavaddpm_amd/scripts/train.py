@@ -214,18 +214,22 @@ class Trainer:
         already on the device is copied device-to-device in stream order and only the scalars go through the pinned
         buffers."""
         key = (tuple(x.shape), x.is_cuda)
-        sg = getattr(self, "_stage", None)
-        if sg is None or sg["key"] != key:
+        stages = self.__dict__.setdefault("_stages", {})
+        sg = stages.get(key)
+        if sg is None:
+            # one staging buffer and one set of captured graphs PER batch shape (the reference's loader ends every epoch with
+            # a short batch: a single slot would re-capture twice per epoch); at most four shapes are kept
+            if len(stages) >= 4:
+                stages.pop(next(iter(stages)))
             B, Dx = x.shape
             n_x = B * Dx
             stage_dev = torch.zeros(n_x + 8, device=self.flat.device, dtype=torch.float32)
             pins = [torch.zeros(n_x + 8, dtype=torch.float32).pin_memory() for _ in range(2)]
-            sg = self._stage = {"key": key, "dev": stage_dev, "x": stage_dev[:n_x].view(B, Dx), "pins": pins, "ev": [None, None],
-                                "lo": n_x if x.is_cuda else 0, "n": n_x + 8,
+            sg = stages[key] = {"key": key, "dev": stage_dev, "x": stage_dev[:n_x].view(B, Dx), "pins": pins, "ev": [None, None],
+                                "lo": n_x if x.is_cuda else 0, "n": n_x + 8, "hyper": stage_dev[n_x:], "graph": None, "cal": None,
                                 "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * n_x) for p in pins]}
             sg["x"].copy_(x)
-            self._hyper_dev = stage_dev[n_x:]
-            self._graph = self._cal_graph = None          # graphs captured on another staging buffer are stale
+        self._hyper_dev = sg["hyper"]                     # what `_adamw_range` bakes into a capture
         return sg
 
     def _fetch_node(self, sg):
@@ -268,10 +272,10 @@ class Trainer:
         CLAVA_TRAIN_DRAWS=torch keeps torch's generator in the graph.  Returns (loss_multi, loss_gauss, optimizer ran)."""
         sg = self._staging(x)
         key = (sg["key"], st.generation)
-        gr = getattr(self, "_graph", None)
+        gr = sg["graph"]
         if gr is None or gr["key"] != key:
-            if getattr(self, "_graph_warm", None) != key:
-                self._graph_warm = key
+            if sg.get("warm") != key:
+                sg["warm"] = key
                 return None
             d = self.diffusion
             net = d._denoise_fn
@@ -324,8 +328,9 @@ class Trainer:
                                             after_blocks=(lambda: self._adamw_range(0, cut)) if cut > 0 else None)
                 if graph_opt:
                     self._adamw_range(cut, self.layout.total)
-            gr = self._graph = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise),
+            gr = sg["graph"] = {"key": key, "graph": graph, "x": static_x, "lm": lm, "lg": lg, "keep": (saved, d_out, x_in, t, noise),
                                 "opt": graph_opt}
+        self._graph = gr                                  # the split graph last replayed (tests look at its tensors)
         self._replay(sg, gr["graph"], x, gr["opt"])
         st.steps_since += 1
         return gr["lm"], gr["lg"], gr["opt"]
@@ -339,12 +344,12 @@ class Trainer:
         if self.dist is not None or os.environ.get("CLAVA_TRAIN_GRAPH_OPT", "1") == "0" or not _tr.DEVICE_DRAWS or st.flag is None:
             return None
         sg = self._staging(x)
-        gr = getattr(self, "_cal_graph", None)
+        gr = sg["cal"]
         d = self.diffusion
         net = d._denoise_fn
-        if gr is None or gr["key"] != sg["key"]:
-            if getattr(self, "_cal_warm", None) != sg["key"]:
-                self._cal_warm = sg["key"]
+        if gr is None:
+            if not sg.get("cal_warm"):
+                sg["cal_warm"] = True
                 return None
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -357,8 +362,9 @@ class Trainer:
                 _tr.denoiser_backward(net, saved, d_out, self.layout, self.slabs, collect=gs)
                 stats = st.calibration_stats(net.stack()[0], saved[4], gs, x_in, d_out, d.num_numerical_features)
                 self._adamw_range(0, self.layout.total)
-            gr = self._cal_graph = {"key": sg["key"], "graph": graph, "lm": lm, "lg": lg, "stats": stats, "n": len(saved[4]),
-                                    "keep": (saved, d_out, x_in, t, noise, gs)}
+            gr = sg["cal"] = {"key": sg["key"], "graph": graph, "lm": lm, "lg": lg, "stats": stats, "n": len(saved[4]),
+                              "keep": (saved, d_out, x_in, t, noise, gs)}
+        self._cal_graph = gr
         self._replay(sg, gr["graph"], x, True)
         st.calibrate_from(gr["stats"], gr["n"], bool(d.num_numerical_features))
         return gr["lm"], gr["lg"]
@@ -450,6 +456,8 @@ class Trainer:
                 self._split.flag.zero_()
                 self._force_f32 = len(replay) - 1
                 self._graph = None
+                for sg_ in getattr(self, "_stages", {}).values():
+                    sg_["graph"] = None
                 snap = None
                 continue
             if pending is not None:

@@ -207,10 +207,15 @@ class SplitTrainState:
         return ss[which]
 
     def buf(self, key, rows, cols, device):
-        b = self.bufs.get(key)
+        """The persistent split buffer `key` of this shape.  Activation / gradient buffers are kept PER SHAPE: a captured
+        step holds their addresses, and a trainer that alternates batch shapes (the short last batch of every epoch)
+        replays one graph per shape -- replacing a buffer would hand its memory back to the allocator under a live graph.
+        Weight operands ("w", l) / ("wt", l) do not depend on the batch and are looked up by their plain key."""
+        k = key if key[0] in ("w", "wt") else key + (rows, cols)
+        b = self.bufs.get(k)
         if b is None or (b.rows, b.cols) != (rows, cols):
             b = ops.split_empty(rows, cols, 0, device)
-            self.bufs[key] = b
+            self.bufs[k] = b
         return b
 
     def pack_weights(self, ws, wide, device, gather=False):

@@ -373,3 +373,32 @@ def test_captured_steps_follow_the_eager_trajectory():
         assert float((ea - eb).abs().max()) < 2e-5 * float(eb.abs().max())
     finally:
         split_nets.set_gemm_mode(prev)
+
+
+def test_alternating_batch_shapes_keep_their_captured_graphs():
+    """The reference's loader ends every epoch with a short batch: each batch shape keeps its own staging buffers and
+    captured graphs, so alternating shapes replay instead of re-capturing."""
+    from clavaddpm_amd import split_nets
+    prev = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode("f16x3")
+    try:
+        torch.manual_seed(0)
+        net = MLPDiffusion(2, 0, "none", {"d_layers": [128, 256, 128], "dropout": 0.0}).to(DEV).train()
+        d = GaussianMultinomialDiffusion(np.array([0]), 2, net, num_timesteps=1000, device=torch.device(DEV)).to(DEV).train()
+        tr = Trainer(d, None, lr=1e-3, weight_decay=0.0, steps=10 ** 6, device=torch.device(DEV))
+        g = torch.Generator().manual_seed(1)
+        full, short = torch.randn(512, 2, generator=g), torch.randn(160, 2, generator=g)
+        y = lambda x: {"y": torch.zeros(len(x), dtype=torch.long)}
+        for x in [full] * 4 + [short] * 3:              # calibration, warm-up and capture of both shapes
+            tr._run_step(x, y(x))
+        graphs = {k: sg["graph"]["graph"] for k, sg in tr._stages.items()}
+        assert len(graphs) == 2 and all(v is not None for v in graphs.values())
+        w0 = tr.flat.clone()
+        for x in [full, full, short, full, short, short, full]:
+            lm, lg = tr._run_step(x, y(x))
+            assert bool(torch.isfinite(lg))
+        assert {k: sg["graph"]["graph"] for k, sg in tr._stages.items()} == graphs       # replayed, not re-captured
+        assert tr.opt_step == 14 and int(tr._step_word.item()) == 14 == tr._host_word
+        assert bool(torch.isfinite(tr.flat).all()) and not torch.equal(tr.flat, w0)
+    finally:
+        split_nets.set_gemm_mode(prev)
