@@ -9,11 +9,11 @@
 // the split image of x_in, 137 MB per step -- is never built (its forward counterpart: cat_input.hip).
 //
 // A workgroup owns (feature, batch range, range of <= 128 classes); thread c owns column c of an LDS table [classes][129]
-// and walks the rows of the batch range in order, adding g[b][c] to the row of b's class with ds_add_f32 (no return value:
-// the LDS unit does the add, nothing waits for it; a read-add-write in registers cost a 350-cycle dependent round trip per
-// row, 150 us in all).  Only thread c ever touches column c and a wave's LDS operations execute in order, so every sum
-// has a fixed order: slabs are bitwise reproducible.  G comes from the bias-gradient slabs of the same layer (the caller
-// computes them first).  Written out with the lanes along the classes (contiguous in dW's rows).
+// and walks the rows of the batch range in order, adding g[b][c] to the row of b's class (a plain LDS read-add-write;
+// ds_add_f32 was tried and is 2x slower here: LDS float adds retire at ~600 cycles per wave instruction).  Only thread c
+// ever touches column c and a wave's LDS operations execute in order, so every sum has a fixed order: slabs are bitwise
+// reproducible, no atomics.  G comes from the bias-gradient slabs of the same layer (the caller computes them first).
+// Written out with the lanes along the classes (contiguous in dW's rows).
 #include "clava_hip.h"
 #include "common.h"
 
