@@ -507,6 +507,9 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
                         "gemm_f16x3: %d slabs of %d k blocks do not cover Kp=%d", slabs, g.kb_per_slab, g.Kp);
         CLAVA_CHECK_ARG(g.slab_stride >= (long long)(g.M - 1) * g.ldc + g.N, "gemm_f16x3: slab stride too small");
     }
+    // at most 16 outputs, float32 result (a head, the last input-gradient product): memory bound, no tile to fill
+    static const bool narrow_on = !(getenv("CLAVA_NARROW_SPLIT") && getenv("CLAVA_NARROW_SPLIT")[0] == '0');
+    if (cfg < 0 && narrow_on && clava_narrow_split_ok(g)) return clava_launch_narrow_split(g, stream);
     if (cfg < 0) cfg = pick_cfg(g.M * slabs, g.N, slabs > 1 ? g.kb_per_slab * 32 : g.Kp);
     const TileCfg& tc = kCfgs[cfg];
     const int lds = tc.ns * (tc.bn + tc.bm) * 128;

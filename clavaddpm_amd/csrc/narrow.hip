@@ -12,6 +12,7 @@
 // Fixed summation orders, no atomics: results are bitwise reproducible.  D <= 16.
 #include "clava_hip.h"
 #include "common.h"
+#include "split.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -213,6 +214,62 @@ __global__ void __launch_bounds__(256) narrow_wgrad_kernel(const float* __restri
             ((parta[0][threadIdx.x] + parta[1][threadIdx.x]) + parta[2][threadIdx.x]) + parta[3][threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------- narrow product from split rows
+// out[b][d] = alpha * (scale_acc * sum_k A[b][k] W[d][k] + bias[d] + bias2[d]) for N <= 16 outputs, A and W as split rows
+// (split.h): the denoiser head and the last input-gradient product of the guidance classifier in the SAMPLING chain.  On
+// the tiled MFMA kernel these use a 64-column tile for 2 useful columns and 157 workgroups walking K in 32-deep blocks
+// (26 us at 20000 rows); here 16 lanes read a row's planes once (4 * Kp bytes), hi + lo is exact in float32, plain FMAs.
+template <int DM>
+__global__ void __launch_bounds__(256) narrow_split_kernel(SplitGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [N][Kp], hi + lo
+    const int Kp = g.Kp, D = g.N;
+    for (int i = threadIdx.x; i < D * (Kp >> 2); i += 256) {
+        const int d = i / (Kp >> 2), k = (i - d * (Kp >> 2)) << 2;
+        const char* p = g.W + (long long)d * g.pitchW + (k >> 5) * 128 + ((k & 31) << 1);
+        const h4 hi = *reinterpret_cast<const h4*>(p), lo = *reinterpret_cast<const h4*>(p + 64);
+        *reinterpret_cast<f4*>(wl + d * Kp + k) = f4{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2],
+                                                    (float)hi[3] + (float)lo[3]};
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const char* ar = g.A + (row < g.M ? row : (long long)g.M - 1) * g.pitchA;
+    float acc[DM];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) acc[d] = 0.f;
+    for (int k = 4 * sub; k < Kp; k += 64) {
+        const char* p = ar + (k >> 5) * 128 + ((k & 31) << 1);
+        const h4 hi = *reinterpret_cast<const h4*>(p), lo = *reinterpret_cast<const h4*>(p + 64);
+        const float x0 = (float)hi[0] + (float)lo[0], x1 = (float)hi[1] + (float)lo[1], x2 = (float)hi[2] + (float)lo[2],
+                    x3 = (float)hi[3] + (float)lo[3];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (d < D) {
+                const f4 wv = *reinterpret_cast<const f4*>(wl + d * Kp + k);
+                acc[d] = fmaf(x0, wv[0], acc[d]);
+                acc[d] = fmaf(x1, wv[1], acc[d]);
+                acc[d] = fmaf(x2, wv[2], acc[d]);
+                acc[d] = fmaf(x3, wv[3], acc[d]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DM; ++d)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc[d] += __shfl_xor(acc[d], o, 64);
+    if (sub == 0 && row < g.M) {
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (d < D) {
+                float b = 0.f;
+                if (g.bias) b += g.bias[d];
+                if (g.bias2) b += g.bias2[d];
+                g.out_f32[row * g.ldc + d] = g.alpha * (acc[d] * g.scale_acc + b);
+            }
+        }
+    }
+}
+
 template <typename F>
 int by_width(int D, F&& f) {
     if (D <= 2) return f(std::integral_constant<int, 2>());
@@ -222,6 +279,22 @@ int by_width(int D, F&& f) {
 }
 
 }  // namespace
+
+bool clava_narrow_split_ok(const SplitGemmArgs& g) {
+    return g.N >= 1 && g.N <= DMAX && g.out_f32 && !g.out_split && !g.mask && g.slabs <= 1 && g.act == CLAVA_ACT_NONE &&
+           (long long)g.N * g.Kp <= 16384 && g.pitchA % 8 == 0 && g.pitchW % 8 == 0 &&
+           (reinterpret_cast<unsigned long long>(g.A) & 7) == 0 && (reinterpret_cast<unsigned long long>(g.W) & 7) == 0;
+}
+
+int clava_launch_narrow_split(const SplitGemmArgs& g, hipStream_t stream) {
+    CLAVA_CHECK_ARG(clava_narrow_split_ok(g) && g.M > 0 && g.Kp > 0 && g.Kp % 32 == 0 && g.ldc >= g.N, "narrow_split: unsupported product");
+    ProfScope prof(PROF_MISC, 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp), 4.0 * g.M * ((double)g.Kp + g.N), stream);
+    return by_width(g.N, [&](auto dm) {
+        hipLaunchKernelGGL((narrow_split_kernel<decltype(dm)::value>), dim3((g.M + 15) / 16), dim3(256), (size_t)g.N * g.Kp * 4, stream, g);
+        CLAVA_CHECK_LAUNCH("narrow_split");
+        return (int)CLAVA_OK;
+    });
+}
 
 extern "C" {
 

@@ -50,6 +50,11 @@ struct SplitGemmArgs {
 // cfg < 0: pick the tile configuration for the shape; otherwise force configuration `cfg` (tools/bench_f16x3.py)
 int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream);
 int clava_gemm_f16x3_config_count();
+// products with at most 16 outputs and a float32 result (heads, the last input-gradient product): a memory-bound kernel that
+// reads the split rows once (narrow.hip); clava_launch_gemm_f16x3 routes to it when the shape qualifies (CLAVA_NARROW_SPLIT=0:
+// never)
+bool clava_narrow_split_ok(const SplitGemmArgs& g);
+int clava_launch_narrow_split(const SplitGemmArgs& g, hipStream_t stream);
 // weight-gradient product from batch-major operands (gemm_f16x3_tn.hip): A = dy [Kp rows = batch][M = n_out columns],
 // W = x [Kp][N = k_in], out_f32[n_out][k_in] (slabs over the batch axis as above)
 int clava_launch_gemm_f16x3_tn(SplitGemmArgs g, hipStream_t stream);

@@ -196,3 +196,20 @@ def test_time_embedding_backward_kernel_matches_float64(B):
     sg = torch.sigmoid(zd)
     ref = (gr.double() @ w2.double()) * (sg * (1 + zd * (1 - sg)))
     assert relerr(dz, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,K,N", [(20000, 512, 2), (777, 128, 5), (64, 1024, 16), (33, 40, 1)])
+def test_narrow_product_from_split_rows_matches_float64(M, K, N):
+    """clava_gemm_f16x3 with at most 16 outputs and a float32 result takes the memory-bound kernel of csrc/narrow.hip (the
+    denoiser head and the guidance classifier's last input-gradient product of the sampling chain): against float64 at the
+    split products' own bar, and against the tiled MFMA kernel (forced by a tile configuration) on the same operands."""
+    g = _gen(M + K + N)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    xs, wsp = ops.split_pack(x, 4), ops.split_pack(w, 9)
+    out = ops.linear_f16x3(xs, wsp, b, out_f32=True)
+    ref = x.double() @ w.double().T + b.double()
+    assert relerr(out, ref) < 2e-6
+    tiled = ops.linear_f16x3(xs, wsp, b, out_f32=True, tile_config=7)
+    assert relerr(out, tiled) < 2e-6
