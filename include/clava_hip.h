@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 108
+#define CLAVA_HIP_VERSION 109
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0
