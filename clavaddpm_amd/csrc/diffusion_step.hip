@@ -33,7 +33,6 @@ __global__ void __launch_bounds__(256) gauss_step_kernel(GaussStepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ multinomial
-constexpr int MAX_LDS_FEATURES = 1024;
 
 // One (row, feature) block per group of G lanes.  G = 64: one wavefront per block, classes lane-strided, the block's
 // size, offset and hot class in scalar registers.  G = 8 / 16 / 32 (features of up to 8 / 16 / 32 classes): 8 / 4 / 2
@@ -226,16 +225,13 @@ __device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const
     }
 }
 
-// Lane-group width of a feature: the smallest of 8 / 16 / 32 / 64 lanes that holds one class per lane (64 beyond).
-__device__ __forceinline__ int feature_bucket(int K) { return K <= 8 ? 0 : K <= 16 ? 1 : K <= 32 ? 2 : 3; }
-
 template <int MODE>
 __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) {
     __shared__ int s_off[MAX_LDS_FEATURES + 1];
     __shared__ float s_logk[MAX_LDS_FEATURES];
     __shared__ float s_side[2 * MAX_LDS_FEATURES];
     __shared__ int s_perm[MAX_LDS_FEATURES];       // features ordered by lane-group width
-    __shared__ int s_cnt[4], s_fill[4];
+    __shared__ int s_start[5];
     const bool staged = a.m <= MAX_LDS_FEATURES;
     const int wave_lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -252,13 +248,10 @@ __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) 
         }
         return;
     }
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = s_fill[threadIdx.x] = 0;
-    __syncthreads();
     for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
     for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
         const float logk = a.log_k[i];
         s_logk[i] = logk;
-        atomicAdd(&s_cnt[feature_bucket(a.offsets[i + 1] - a.offsets[i])], 1);
         if (MODE != MULTI_MODE_INIT && !a.t_rows) {     // one t for the whole launch: the side factors depend on the feature only
             const int tp = (MODE == MULTI_MODE_QSAMPLE) ? a.t : max(a.t - 1, 0);
             const float la = (MODE == MULTI_MODE_QSAMPLE) ? a.s.log_cumprod_alpha[tp] : a.s.log_alpha[a.t];
@@ -270,26 +263,9 @@ __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) 
     __syncthreads();
     // features grouped by lane-group width (their order inside a group does not matter: every draw is keyed by the
     // feature, not by where it runs); a wavefront work item = one 64-lane block, or 2 / 4 / 8 narrower blocks of one row
-    const int n0 = s_cnt[0], n1 = s_cnt[1], n2 = s_cnt[2], n3 = s_cnt[3];
-    const int st1 = n0, st2 = n0 + n1, st3 = n0 + n1 + n2;
-    // The order must be THE SAME in every workgroup: a work item is "features perm[8w .. 8w+7] of row r", and the items of
-    // a row are spread over the whole grid.  (Positions handed out by LDS atomics depend on which wavefront gets there
-    // first once m > 64: workgroups then disagreed about what item w is and some (row, feature) blocks were never drawn.)
-    // One wavefront ranks the features in index order with ballots: a stable counting sort.
-    if (threadIdx.x < 64) {
-        int base[4] = {0, st1, st2, st3};
-        for (int i0 = 0; i0 < a.m; i0 += 64) {
-            const int i = i0 + (int)threadIdx.x;
-            const int bk = (i < a.m) ? feature_bucket(s_off[i + 1] - s_off[i]) : -1;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const unsigned long long mask = __ballot(bk == b);
-                if (bk == b) s_perm[base[b] + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = i;
-                base[b] += __popcll(mask);
-            }
-        }
-    }
-    __syncthreads();
+    order_features_by_width(a.m, s_off, s_perm, s_start);
+    const int st1 = s_start[1], st2 = s_start[2], st3 = s_start[3];
+    const int n0 = st1, n1 = st2 - st1, n2 = st3 - st2, n3 = a.m - st3;
     // one loop per width (a single loop over mixed items would keep all four variants' registers live at once)
     multinomial_bucket<8, MODE>(a, s_off, s_logk, s_side, s_perm, n0, wave0, n_waves);
     multinomial_bucket<16, MODE>(a, s_off, s_logk, s_side, s_perm + st1, n1, wave0, n_waves);

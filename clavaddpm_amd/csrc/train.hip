@@ -6,6 +6,7 @@
 // their autograd backward down to the denoiser output, torch.optim.AdamW.step (scripts/train.py:17, 38) and
 // update_ema (scripts/utils_train.py:20-29).  Every reduction runs in a fixed order: results are bitwise
 // reproducible from run to run (no float atomics).
+#include <cstdlib>
 #include "rng.h"
 #include "step.h"
 #include "wave.h"
@@ -46,6 +47,7 @@ struct MLossArgs {
     float pt;                             // 1 / T as float32 ('uniform' sample_time, :589-593)
     float* loss_terms;                    // [B, m]: Lt / pt + kl_prior of this (row, feature) block
     float* d_logits; int ld_d;            // gradient of mean_b( sum_f loss_terms / m ) w.r.t. logits
+    int pack;                             // 0: one wavefront per block whatever its width (CLAVA_MLOSS_PACK=0)
 };
 
 // Per-block (wave-uniform) quantities.  Everything that depends on a class only through "is it the clean category" /
@@ -216,59 +218,171 @@ __device__ __forceinline__ void loss_block_streamed(const MLossArgs& a, LBlock& 
     }
 }
 
-__global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
-    const int lane = threadIdx.x & 63;
-    const long long n_pairs = (long long)a.B * a.m;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-    // a stride coprime with m makes every wavefront walk through all the features (block costs differ by up to 16x)
-    auto gcd = [](long long x, long long y) { while (y) { const long long r = x % y; x = y; y = r; } return x; };
-    while (n_waves > 1 && gcd(n_waves, a.m) != 1) --n_waves;
-    if (wave0 >= n_waves || wave0 >= n_pairs) return;
-    const int T = a.s.T;
-    const float lca_T = a.s.log_cumprod_alpha[T - 1], l1mca_T = a.s.log_1_min_cumprod_alpha[T - 1];
-    // (row, feature) advance by n_waves pairs per iteration without a division in the loop
-    int row = (int)(wave0 / a.m), f = (int)(wave0 - (long long)row * a.m);
-    const int d_row = (int)(n_waves / a.m), d_f = (int)(n_waves - (long long)d_row * a.m);
-    for (; row < a.B; row += d_row, f += d_f) {
-        if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
-        const size_t pair = (size_t)row * a.m + f;
-        const int o = __builtin_amdgcn_readfirstlane(a.offsets[f]);
-        LBlock b;
-        b.K = __builtin_amdgcn_readfirstlane(a.offsets[f + 1]) - o;
-        const float logk = a.log_k[f];
-        b.t = __builtin_amdgcn_readfirstlane((int)a.t_rows[row]);
-        b.hot0 = __builtin_amdgcn_readfirstlane(a.idx0[pair]);
-        b.hott = __builtin_amdgcn_readfirstlane(a.idxt[pair]);
-        b.lg = a.logits + (size_t)row * a.ld_logits + o;
-        b.d = a.d_logits + (size_t)row * a.ld_d + o;
-        const int tp = max(b.t - 1, 0);
-        b.lca_p = a.s.log_cumprod_alpha[tp];
-        b.uni_p = a.s.log_1_min_cumprod_alpha[tp] - logk;
-        const float la_t = a.s.log_alpha[b.t], uni_t = a.s.log_1_min_alpha[b.t] - logk;
-        // The block's six log-add-exps -- q1 (hot, cold), ev at the clean / any other class, the prior's lq (hot, cold) -- in
-        // ONE evaluation: lane j computes the j-th (the same function on the same arguments as six scalar calls: identical
-        // bits), then the results are read back by lane.  The per-block set-up was ~40 % of the kernel's instructions at the
-        // scale-sweep shape, where the kernel is instruction bound on blocks of a few classes.
-        {
-            const float hot_cold = (lane & 1) ? LOG_TINY : 0.f;
-            const int which = lane >> 1;
-            const float x = hot_cold + (which == 0 ? la_t : which == 1 ? b.lca_p : lca_T);
-            const float y = which == 0 ? uni_t : which == 1 ? b.uni_p : l1mca_T - logk;
-            const float r = log_add_exp_acc(x, y);
-            const float kl = exp_nonpos(r) * (r + logk);
-            auto rl = [](float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
-            b.q1_hot = rl(r, 0);
-            b.q1_cold = rl(r, 1);
-            b.evt_hot = b.t == 0 ? 0.f : rl(r, 2);                 // ev is the identity at t = 0
-            b.evt_cold = b.t == 0 ? LOG_TINY : rl(r, 3);
-            b.klp_hot = rl(kl, 4);
-            b.klp_cold = rl(kl, 5);
+// 64 / G blocks of up to G classes of ONE row per wavefront, one class per lane: the per-class work, the ten group
+// reductions and the three normalisers of a block cost the same ~700 wave instructions whether the wavefront holds one
+// block of 3 classes or eight of them, and the kernel is VALU bound (207 M wave instructions at the scale-sweep shape =
+// 385 us at one instruction per SIMD per 4 cycles: measured 400).  The same functions on the same arguments as the
+// wavefront-wide form below -- the two-valued factors are evaluated per lane instead of per block and selected.
+struct RowScalars {                // wave-uniform: every block of a work item belongs to one row
+    int t;
+    float lca_p, l1mca_p, la_t, l1ma_t, lca_T, l1mca_T;
+};
+
+template <int G>
+__device__ __forceinline__ void loss_block_packed(const MLossArgs& a, const RowScalars& r, int row, int f, bool active, int o, int K,
+                                                  float logk) {
+    const int c = (int)(threadIdx.x & (G - 1));
+    const size_t pair = (size_t)row * a.m + f;
+    const int hot0 = a.idx0[pair], hott = a.idxt[pair];
+    const bool valid = c < K;
+    float v = valid ? a.logits[(size_t)row * a.ld_logits + o + c] : -INFINITY;
+    const float uni_p = r.l1mca_p - logk;
+    const float h0 = (c == hot0) ? 0.f : LOG_TINY, ht = (c == hott) ? 0.f : LOG_TINY;
+    const float q1 = log_add_exp_acc(ht + r.la_t, r.l1ma_t - logk);                      // q_pred_one_timestep(x_t)
+    const float evt = r.t == 0 ? h0 : log_add_exp_acc(h0 + r.lca_p, uni_p);               // q_pred(x_0, t-1), identity at t = 0
+    const float lq = log_add_exp_acc(h0 + r.lca_T, r.l1mca_T - logk);                     // prior KL (:544-553)
+    const float klp_c = exp_nonpos(lq) * (lq + logk);
+    const float un_t = evt + q1;
+    auto counted_log_total = [&](float x, float mx) {          // CountedSum over the group's valid lanes
+        const float d = x - mx;
+        const float n_max = (valid && d == 0.f) ? 1.0f : 0.f;
+        const float rest = (valid && d != 0.f) ? exp_nonpos(d) : 0.f;
+        return log_sum_counted(group_sum<G>(n_max), group_sum<G>(rest));
+    };
+    const float mx = group_max<G>(v);
+    const float lsum = counted_log_total(v, mx);
+    v = (v - mx) - lsum;                                                                 // predict_start
+    const float e = r.t == 0 ? v : log_add_exp_acc(v + r.lca_p, uni_p);
+    const float un_m = e + q1;
+    const float mm = group_max<G>(valid ? un_m : -INFINITY), mt = group_max<G>(valid ? un_t : -INFINITY);
+    const float lse_m = mm + counted_log_total(un_m, mm), lse_t = mt + counted_log_total(un_t, mt);
+    const float lm = un_m - lse_m;
+    float w = 0.f, loss = 0.f;
+    if (valid) {
+        if (r.t == 0) {
+            w = (c == hot0) ? 1.0f : 1e-30f;
+            loss = -w * lm;
+        } else {
+            const float lt = un_t - lse_t;
+            w = exp_nonpos(lt);
+            loss = w * (lt - lm);
         }
-        if (b.K <= 256) loss_block_cached<4>(a, b, lane, pair);
-        else if (b.K <= 1024) loss_block_cached<16>(a, b, lane, pair);
-        else loss_block_streamed(a, b, lane, pair);
     }
+    const float W = group_sum<G>(w);
+    loss = group_sum<G>(loss);
+    const float klp = group_sum<G>(valid ? klp_c : 0.f);
+    if (active && c == 0) a.loss_terms[pair] = loss / a.pt + klp;
+    float gl = 0.f;
+    if (valid) gl = (-w + W * exp_nonpos(lm)) * (r.t == 0 ? 1.0f : exp_nonpos((v + r.lca_p) - e));
+    const float S = group_sum<G>(gl);
+    const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
+    if (active && valid) a.d_logits[(size_t)row * a.ld_d + o + c] = (gl - exp_nonpos(v) * S) * scale;
+}
+
+// One (row, feature) block per wavefront: per-block quantities in scalar registers.
+__device__ __forceinline__ void loss_block_wave(const MLossArgs& a, const RowScalars& r, int row, int f, int lane) {
+    const size_t pair = (size_t)row * a.m + f;
+    const int o = __builtin_amdgcn_readfirstlane(a.offsets[f]);
+    LBlock b;
+    b.K = __builtin_amdgcn_readfirstlane(a.offsets[f + 1]) - o;
+    const float logk = a.log_k[f];
+    b.t = r.t;
+    b.hot0 = __builtin_amdgcn_readfirstlane(a.idx0[pair]);
+    b.hott = __builtin_amdgcn_readfirstlane(a.idxt[pair]);
+    b.lg = a.logits + (size_t)row * a.ld_logits + o;
+    b.d = a.d_logits + (size_t)row * a.ld_d + o;
+    b.lca_p = r.lca_p;
+    b.uni_p = r.l1mca_p - logk;
+    const float uni_t = r.l1ma_t - logk;
+    // The block's six log-add-exps -- q1 (hot, cold), ev at the clean / any other class, the prior's lq (hot, cold) -- in
+    // ONE evaluation: lane j computes the j-th (the same function on the same arguments as six scalar calls: identical
+    // bits), then the results are read back by lane.
+    {
+        const float hot_cold = (lane & 1) ? LOG_TINY : 0.f;
+        const int which = lane >> 1;
+        const float x = hot_cold + (which == 0 ? r.la_t : which == 1 ? b.lca_p : r.lca_T);
+        const float y = which == 0 ? uni_t : which == 1 ? b.uni_p : r.l1mca_T - logk;
+        const float lae = log_add_exp_acc(x, y);
+        const float kl = exp_nonpos(lae) * (lae + logk);
+        auto rl = [](float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); };
+        b.q1_hot = rl(lae, 0);
+        b.q1_cold = rl(lae, 1);
+        b.evt_hot = b.t == 0 ? 0.f : rl(lae, 2);                 // ev is the identity at t = 0
+        b.evt_cold = b.t == 0 ? LOG_TINY : rl(lae, 3);
+        b.klp_hot = rl(kl, 4);
+        b.klp_cold = rl(kl, 5);
+    }
+    if (b.K <= 256) loss_block_cached<4>(a, b, lane, pair);
+    else if (b.K <= 1024) loss_block_cached<16>(a, b, lane, pair);
+    else loss_block_streamed(a, b, lane, pair);
+}
+
+__device__ __forceinline__ RowScalars row_scalars(const MLossArgs& a, int row, float lca_T, float l1mca_T) {
+    RowScalars r;
+    r.t = __builtin_amdgcn_readfirstlane((int)a.t_rows[row]);
+    const int tp = max(r.t - 1, 0);
+    r.lca_p = a.s.log_cumprod_alpha[tp];
+    r.l1mca_p = a.s.log_1_min_cumprod_alpha[tp];
+    r.la_t = a.s.log_alpha[r.t];
+    r.l1ma_t = a.s.log_1_min_alpha[r.t];
+    r.lca_T = lca_T;
+    r.l1mca_T = l1mca_T;
+    return r;
+}
+
+// All (row, feature) blocks of the `n_feat` features listed in `perm` (null: features 0 .. n_feat-1), 64 / G blocks of one
+// row per wavefront work item.
+template <int G>
+__device__ __forceinline__ void loss_bucket(const MLossArgs& a, const int* s_off, const float* s_logk, const int* perm, int n_feat,
+                                            long long wave0, long long n_waves) {
+    constexpr int PER = 64 / G;
+    const int W = (n_feat + PER - 1) / PER;                 // work items per row
+    if (W == 0) return;
+    // a stride coprime with W makes every wavefront walk through all the features of the bucket (block costs differ by
+    // up to 16x)
+    auto gcd = [](long long x, long long y) { while (y) { const long long q = x % y; x = y; y = q; } return x; };
+    while (n_waves > 1 && gcd(n_waves, W) != 1) --n_waves;
+    if (wave0 >= n_waves || wave0 >= (long long)a.B * W) return;
+    const int lane = threadIdx.x & 63, sub = lane / G;
+    const float lca_T = a.s.log_cumprod_alpha[a.s.T - 1], l1mca_T = a.s.log_1_min_cumprod_alpha[a.s.T - 1];
+    // (row, item) advance by n_waves items per iteration without a division in the loop
+    int row = (int)(wave0 / W), w = (int)(wave0 - (long long)row * W);
+    const int d_row = (int)(n_waves / W), d_w = (int)(n_waves - (long long)d_row * W);
+    for (; row < a.B; row += d_row, w += d_w) {
+        if (w >= W) { w -= W; ++row; if (row >= a.B) break; }
+        const RowScalars r = row_scalars(a, row, lca_T, l1mca_T);
+        if (G == 64) {
+            loss_block_wave(a, r, row, perm ? perm[w] : w, lane);
+        } else {
+            const int fi = w * PER + sub;
+            const int f = perm[min(fi, n_feat - 1)];        // a group beyond the bucket repeats its last feature and stores nothing
+            const int o = s_off[f];
+            loss_block_packed<G>(a, r, row, f, fi < n_feat, o, s_off[f + 1] - o, s_logk[f]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
+    __shared__ int s_off[MAX_LDS_FEATURES + 1];
+    __shared__ float s_logk[MAX_LDS_FEATURES];
+    __shared__ int s_perm[MAX_LDS_FEATURES];
+    __shared__ int s_start[5];
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    if (a.m > MAX_LDS_FEATURES || !a.pack) {            // more features than the LDS tables hold: one wavefront per block
+        loss_bucket<64>(a, nullptr, nullptr, nullptr, a.m, wave0, n_waves);
+        return;
+    }
+    for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
+    for (int i = threadIdx.x; i < a.m; i += blockDim.x) s_logk[i] = a.log_k[i];
+    __syncthreads();
+    order_features_by_width(a.m, s_off, s_perm, s_start);
+    const int st1 = s_start[1], st2 = s_start[2], st3 = s_start[3];
+    // one loop per width (a single loop over mixed items would keep every variant's registers live at once)
+    loss_bucket<8>(a, s_off, s_logk, s_perm, st1, wave0, n_waves);
+    loss_bucket<16>(a, s_off, s_logk, s_perm + st1, st2 - st1, wave0, n_waves);
+    loss_bucket<32>(a, s_off, s_logk, s_perm + st2, st3 - st2, wave0, n_waves);
+    loss_bucket<64>(a, s_off, s_logk, s_perm + st3, a.m - st3, wave0, n_waves);
 }
 
 // ---------------------------------------------------------------------------------------------- reductions
@@ -462,6 +576,8 @@ int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int su
     MLossArgs a;
     a.s = *sched; a.B = B; a.m = m; a.sumK = sumK; a.logits = logits; a.ld_logits = ld_logits; a.idx0 = idx0; a.idxt = idxt;
     a.t_rows = t_rows; a.offsets = offsets; a.log_k = log_k; a.pt = pt; a.loss_terms = loss_terms; a.d_logits = d_logits; a.ld_d = ld_d;
+    static const int pack_env = [] { const char* e = getenv("CLAVA_MLOSS_PACK"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.pack = pack_env;
     const long long blocks = ((long long)B * m + 3) / 4;
     // persistent grid: as many workgroups as the chip holds at once, so that every wavefront averages over many blocks
     static int resident[64] = {};

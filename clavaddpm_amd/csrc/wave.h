@@ -99,4 +99,42 @@ __device__ __forceinline__ float log_add_exp(float x, float y) {
     return m + log_pos(1.0f + exp_nonpos(-fabsf(x - y)));
 }
 
+// ---- (row, feature) blocks packed into lane groups (categorical step kernel, multinomial loss kernel) ----
+constexpr int MAX_LDS_FEATURES = 1024;
+
+// Lane-group width of a feature: the smallest of 8 / 16 / 32 / 64 lanes that holds one class per lane (64 beyond).
+__device__ __forceinline__ int feature_bucket(int K) { return K <= 8 ? 0 : K <= 16 ? 1 : K <= 32 ? 2 : 3; }
+
+// Features ordered by lane-group width: s_perm lists them bucket by bucket, s_start[b] .. s_start[b + 1] is bucket b.
+// Called by every thread of the workgroup once s_off (the m + 1 class offsets, m <= MAX_LDS_FEATURES) is filled and
+// synchronised; returns synchronised.  The order must be THE SAME in every workgroup -- a work item is "features
+// perm[8w .. 8w+7] of row r" and the items of a row are spread over the whole grid -- so one wavefront ranks the features
+// in index order with ballots (a stable counting sort; positions handed out by LDS atomics depend on which wavefront
+// gets there first once m > 64).
+__device__ __forceinline__ void order_features_by_width(int m, const int* s_off, int* s_perm, int* s_start) {
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        int cnt[4] = {0, 0, 0, 0};
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const int bk = (i < m) ? feature_bucket(s_off[i + 1] - s_off[i]) : -1;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) cnt[b] += __popcll(__ballot(bk == b));
+        }
+        int base[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+        if (lane == 0) { s_start[0] = 0; s_start[1] = base[1]; s_start[2] = base[2]; s_start[3] = base[3]; s_start[4] = m; }
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const int bk = (i < m) ? feature_bucket(s_off[i + 1] - s_off[i]) : -1;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long mask = __ballot(bk == b);
+                if (bk == b) s_perm[base[b] + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+                base[b] += __popcll(mask);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 }  // namespace
