@@ -20,7 +20,7 @@ constexpr float LOG_TINY = -69.07755279541016f;
 // G lanes per row (G = the power of two covering n_num, at most 64): coalesced row segments, fixed-order lane sum.
 __global__ void __launch_bounds__(256) gauss_mse_kernel(int B, int n, int G, const float* __restrict__ out, int ld_out,
                                                         const float* __restrict__ noise, float* __restrict__ loss_rows,
-                                                        float* __restrict__ d_out, int ld_d) {
+                                                        float* __restrict__ d_out, int ld_d, SplitOut ds) {
     const int sub = threadIdx.x & (G - 1);
     const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (row >= B) return;                          // whole groups leave together (G divides 64)
@@ -29,7 +29,8 @@ __global__ void __launch_bounds__(256) gauss_mse_kernel(int B, int n, int G, con
     for (int c = sub; c < n; c += G) {
         const float d = noise[(size_t)row * n + c] - out[(size_t)row * ld_out + c];
         acc += d * d;
-        d_out[(size_t)row * ld_d + c] = -d * gscale;
+        if (d_out) d_out[(size_t)row * ld_d + c] = -d * gscale;
+        if (ds.base) store_split(ds, (int)row, ds.col0 + c, -d * gscale);
     }
     for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (sub == 0) loss_rows[row] = acc / (float)n;
@@ -47,6 +48,7 @@ struct MLossArgs {
     float pt;                             // 1 / T as float32 ('uniform' sample_time, :589-593)
     float* loss_terms;                    // [B, m]: Lt / pt + kl_prior of this (row, feature) block
     float* d_logits; int ld_d;            // gradient of mean_b( sum_f loss_terms / m ) w.r.t. logits
+    SplitOut ds;                          // the gradient as split rows (the head's backward operand), column ds.col0 + class column; or null
     int pack;                             // 0: one wavefront per block whatever its width (CLAVA_MLOSS_PACK=0)
 };
 
@@ -54,7 +56,8 @@ struct MLossArgs {
 // "is it the noised category" takes two values per block and is evaluated once here, not once per class.
 struct LBlock {
     const float* lg;
-    float* d;
+    float* d;                      // null: split rows only
+    int row, col;                  // of the block's first class in the split gradient
     int K, hot0, hott, t;
     float mx, lsum;
     float lca_p, uni_p;            // log cumprod alpha at t-1; log(1 - cumprod alpha_{t-1}) - log K
@@ -168,7 +171,11 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
     for (int j = 0; j < NCH; ++j) {
         if (j == 0 || j * 64 < K) {
             const int c = lane + 64 * j;
-            if (c < K) b.d[c] = (w[j] - exp_nonpos(v[j]) * S) * scale;
+            if (c < K) {
+                const float g = (w[j] - exp_nonpos(v[j]) * S) * scale;
+                if (b.d) b.d[c] = g;
+                if (a.ds.base) store_split(a.ds, b.row, b.col + c, g);
+            }
         }
     }
 }
@@ -214,7 +221,9 @@ __device__ __forceinline__ void loss_block_streamed(const MLossArgs& a, LBlock& 
     const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
     for (int c = lane; c < K; c += 64) {
         const float lpc = lp(c);
-        b.d[c] = (g_lp(c, lpc) - exp_nonpos(lpc) * S) * scale;
+        const float g = (g_lp(c, lpc) - exp_nonpos(lpc) * S) * scale;
+        if (b.d) b.d[c] = g;
+        if (a.ds.base) store_split(a.ds, b.row, b.col + c, g);
     }
 }
 
@@ -276,7 +285,11 @@ __device__ __forceinline__ void loss_block_packed(const MLossArgs& a, const RowS
     if (valid) gl = (-w + W * exp_nonpos(lm)) * (r.t == 0 ? 1.0f : exp_nonpos((v + r.lca_p) - e));
     const float S = group_sum<G>(gl);
     const float scale = (1.0f / a.pt) / ((float)a.m * (float)a.B);
-    if (active && valid) a.d_logits[(size_t)row * a.ld_d + o + c] = (gl - exp_nonpos(v) * S) * scale;
+    if (active && valid) {
+        const float g = (gl - exp_nonpos(v) * S) * scale;
+        if (a.d_logits) a.d_logits[(size_t)row * a.ld_d + o + c] = g;
+        if (a.ds.base) store_split(a.ds, row, a.ds.col0 + o + c, g);
+    }
 }
 
 // One (row, feature) block per wavefront: per-block quantities in scalar registers.
@@ -290,7 +303,9 @@ __device__ __forceinline__ void loss_block_wave(const MLossArgs& a, const RowSca
     b.hot0 = __builtin_amdgcn_readfirstlane(a.idx0[pair]);
     b.hott = __builtin_amdgcn_readfirstlane(a.idxt[pair]);
     b.lg = a.logits + (size_t)row * a.ld_logits + o;
-    b.d = a.d_logits + (size_t)row * a.ld_d + o;
+    b.d = a.d_logits ? a.d_logits + (size_t)row * a.ld_d + o : nullptr;
+    b.row = row;
+    b.col = a.ds.col0 + o;
     b.lca_p = r.lca_p;
     b.uni_p = r.l1mca_p - logk;
     const float uni_t = r.l1ma_t - logk;
@@ -554,28 +569,50 @@ inline int grid_for(long long n, int cap = 4096) {
 
 extern "C" {
 
-int clava_gauss_mse_loss_f32(int B, int n_num, const float* model_out, int ld_out, const float* noise, float* loss_rows,
-                             float* d_out, int ld_d, void* stream) {
-    CLAVA_CHECK_ARG(B > 0 && n_num > 0 && model_out && noise && loss_rows && d_out, "gauss_mse_loss: bad arguments");
+// d_out and / or split rows: the gradient of the step's loss w.r.t. the denoiser output, as float32 and / or in the split
+// layout the head's backward products read (split.h), `col0` = column of the kernel's first column inside those rows
+static bool split_dst_ok(const void* d_split, long long pitch, int shift, int col_end) {
+    if (!d_split) return true;
+    return pitch >= 4LL * ((col_end + 31) & ~31) && pitch % 16 == 0 && (reinterpret_cast<uintptr_t>(d_split) & 15) == 0 && shift >= -126 && shift <= 126;
+}
+static SplitOut split_dst(void* d_split, long long pitch, int shift, int col0, int* overflow) {
+    SplitOut o;
+    o.base = static_cast<char*>(d_split); o.pitch = pitch; o.scale = ldexpf(1.f, shift); o.col0 = col0; o.overflow = overflow;
+    return o;
+}
+
+int clava_gauss_mse_loss_split_f32(int B, int n_num, const float* model_out, int ld_out, const float* noise, float* loss_rows,
+                                   float* d_out, int ld_d, void* d_split, long long pitch, int shift, int* overflow, void* stream) {
+    CLAVA_CHECK_ARG(B > 0 && n_num > 0 && model_out && noise && loss_rows && (d_out || d_split), "gauss_mse_loss: bad arguments");
+    CLAVA_CHECK_ARG(split_dst_ok(d_split, pitch, shift, n_num), "gauss_mse_loss: split rows must be 16-byte aligned and hold n_num columns");
     ProfScope prof(PROF_LOSS, 0.0, 12.0 * B * n_num, (hipStream_t)stream);
     int G = 1;
     while (G < n_num && G < 64) G <<= 1;
     const long long blocks = ((long long)B * G + 255) / 256;
     hipLaunchKernelGGL(gauss_mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, n_num, G, model_out, ld_out,
-                       noise, loss_rows, d_out, ld_d);
+                       noise, loss_rows, d_out, ld_d, split_dst(d_split, pitch, shift, 0, overflow));
     CLAVA_CHECK_LAUNCH("clava_gauss_mse_loss_f32");
     return CLAVA_OK;
 }
 
-int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int sumK, const int* offsets, const float* log_k,
-                               const float* logits, int ld_logits, const int* idx0, const int* idxt,
-                               const long long* t_rows, float pt, float* loss_terms, float* d_logits, int ld_d,
-                               void* stream) {
-    CLAVA_CHECK_ARG(sched && B > 0 && m > 0 && sumK > 0 && offsets && log_k && logits && idx0 && idxt && t_rows && loss_terms && d_logits,
+int clava_gauss_mse_loss_f32(int B, int n_num, const float* model_out, int ld_out, const float* noise, float* loss_rows,
+                             float* d_out, int ld_d, void* stream) {
+    CLAVA_CHECK_ARG(d_out, "gauss_mse_loss: bad arguments");
+    return clava_gauss_mse_loss_split_f32(B, n_num, model_out, ld_out, noise, loss_rows, d_out, ld_d, nullptr, 0, 0, nullptr, stream);
+}
+
+int clava_multinomial_loss_split_f32(const clava_schedule* sched, int B, int m, int sumK, const int* offsets, const float* log_k,
+                                     const float* logits, int ld_logits, const int* idx0, const int* idxt, const long long* t_rows,
+                                     float pt, float* loss_terms, float* d_logits, int ld_d, void* d_split, long long pitch, int shift,
+                                     int col0, int* overflow, void* stream) {
+    CLAVA_CHECK_ARG(sched && B > 0 && m > 0 && sumK > 0 && offsets && log_k && logits && idx0 && idxt && t_rows && loss_terms &&
+                        (d_logits || d_split) && col0 >= 0,
                     "multinomial_loss: bad arguments");
+    CLAVA_CHECK_ARG(split_dst_ok(d_split, pitch, shift, col0 + sumK), "multinomial_loss: split rows must be 16-byte aligned and hold col0 + sumK columns");
     MLossArgs a;
     a.s = *sched; a.B = B; a.m = m; a.sumK = sumK; a.logits = logits; a.ld_logits = ld_logits; a.idx0 = idx0; a.idxt = idxt;
     a.t_rows = t_rows; a.offsets = offsets; a.log_k = log_k; a.pt = pt; a.loss_terms = loss_terms; a.d_logits = d_logits; a.ld_d = ld_d;
+    a.ds = split_dst(d_split, pitch, shift, col0, overflow);
     static const int pack_env = [] { const char* e = getenv("CLAVA_MLOSS_PACK"); return (e && e[0] == '0') ? 0 : 1; }();
     a.pack = pack_env;
     const long long blocks = ((long long)B * m + 3) / 4;
@@ -593,6 +630,15 @@ int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int su
     hipLaunchKernelGGL(multinomial_loss_kernel, dim3((int)(blocks < resident[dev] ? blocks : resident[dev])), dim3(256), 0, (hipStream_t)stream, a);
     CLAVA_CHECK_LAUNCH("clava_multinomial_loss_f32");
     return CLAVA_OK;
+}
+
+int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int sumK, const int* offsets, const float* log_k,
+                               const float* logits, int ld_logits, const int* idx0, const int* idxt,
+                               const long long* t_rows, float pt, float* loss_terms, float* d_logits, int ld_d,
+                               void* stream) {
+    CLAVA_CHECK_ARG(d_logits, "multinomial_loss: bad arguments");
+    return clava_multinomial_loss_split_f32(sched, B, m, sumK, offsets, log_k, logits, ld_logits, idx0, idxt, t_rows, pt, loss_terms, d_logits,
+                                            ld_d, nullptr, 0, 0, 0, nullptr, stream);
 }
 
 int clava_sum_f32(const float* v, long long n, float scale, float* out, void* stream) {

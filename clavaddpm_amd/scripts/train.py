@@ -196,7 +196,8 @@ class Trainer:
                 st.calibrate(net.stack()[0], saved[4], gs, x_in=x_in, d_out=d_out, n_num=d.num_numerical_features)
         else:
             model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st)
-            loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t)
+            loss_multi, loss_gauss, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t,
+                                                              split_out=_tr.loss_split_target(st, saved, model_out), overflow=st.flag)
             overlap = self.dist is not None and os.environ.get("CLAVA_DP_OVERLAP", "1") != "0"
             self._dp_pending = [] if overlap else None
             _tr.denoiser_backward_split(net, saved, d_out, self.layout, self.slabs, st,
@@ -315,7 +316,8 @@ class Trainer:
                 model_out, saved = _tr.denoiser_forward_split(net, x_in, t, st, cat=(idxt, d) if gather else None)
                 # the loss means are summed on a stream the backward joins at its end: nothing in the step waits for them
                 lm, lg, d_out = _tr.loss_and_grad(d, model_out, noise, idx0, idxt, t,
-                                                  aux_stream=st.side_stream(dev, 1) if _tr.TAIL_BRANCHES else None)
+                                                  aux_stream=st.side_stream(dev, 1) if _tr.TAIL_BRANCHES else None,
+                                                  split_out=_tr.loss_split_target(st, saved, model_out), overflow=st.flag)
                 # The optimizer inside the graph, in two launches: the hidden blocks and the head (99.2 % of the parameters)
                 # as soon as their gradients are complete, on the weight-gradient stream -- an HBM-bound kernel beside the
                 # small latency-bound products of proj and the time-embedding branch that end the backward -- and those

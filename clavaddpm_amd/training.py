@@ -452,6 +452,21 @@ def denoiser_forward_split(net, x_in, t, st, cat=None):
     return out, (x_in, te, z1, a1, hs, hsplit, xs, catinfo)
 
 
+LOSS_SPLIT = os.environ.get("CLAVA_TRAIN_LOSS_SPLIT", "1") != "0"
+
+
+def loss_split_target(st, saved, model_out, splits=GRAD_SPLITS):
+    """Where `loss_and_grad` may write the loss gradient as split rows (wide tables, a batch of whole 32-row blocks: the
+    head's backward then consumes nothing but the split operand), or None: the float32 gradient + a pack launch."""
+    M, D = model_out.shape
+    wide = saved[6] is not None or saved[7] is not None
+    if not (LOSS_SPLIT and wide and M % 32 == 0 and wgrad_split_ok(M, splits)):
+        return None
+    b = st.buf(("d",), M, D, model_out.device)       # zero-initialised: the pad columns of the last block stay zero
+    b.shift = st.shift_d
+    return b
+
+
 def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SPLITS, on_layer_done=None, after_blocks=None):
     """`denoiser_backward` with the input-gradient products of layers n-2 .. 1 on clava_gemm_f16x3 and the hidden blocks'
     weight / bias gradients on the batch-major split kernel.  `on_layer_done(prefix)` (data parallel) is called with the
@@ -462,8 +477,11 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
     x_in, te, z1, a1, hs, hsplit, xs, catinfo = saved
     wide = xs is not None or catinfo is not None
     total = layout.total
-    M = d_out.shape[0]
-    dev = d_out.device
+    d_split = d_out if isinstance(d_out, ops.SplitTensor) else None        # loss_and_grad(split_out=...): no float32 gradient
+    M = d_split.rows if d_split is not None else d_out.shape[0]
+    dev = te.device
+    if d_split is not None and not (wide and wgrad_split_ok(M, splits) and M % 32 == 0):
+        raise _lib.ClavaHipError("denoiser_backward_split: a split-row loss gradient needs the wide-table path and a batch of whole 32-row blocks")
 
     def param_grads(prefix, dy, inp):
         wi = layout.index[prefix + ".weight"]
@@ -523,7 +541,7 @@ def denoiser_backward_split(net, saved, d_out, layout, slabs, st, splits=GRAD_SP
 
     # head: parameter gradients and the gradient w.r.t. the last hidden pre-activation
     if wide:
-        ds = ops.split_pack(d_out, st.shift_d, st.flag, out=st.buf(("d",), M, d_out.shape[1], dev))
+        ds = d_split if d_split is not None else ops.split_pack(d_out, st.shift_d, st.flag, out=st.buf(("d",), M, d_out.shape[1], dev))
         param_grads_async(names[n - 1], d_out, hs[n - 2], ds, hsplit[n - 2])
         wh = ws[n - 1]
         wht = st.bufs[("wt", n - 1)]
@@ -713,23 +731,33 @@ def draw_noised_input(diffusion, x, seed, step_counter, dense=True):
     return t, noise, x_in, idx0, idxt
 
 
-def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t, aux_stream=None):
+def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t, aux_stream=None, split_out=None, overflow=None):
     """Both loss means (0-dim device tensors, or None for an absent half) and d(loss_multi + loss_gauss)/d(model_out).
     `aux_stream`: the reductions to the two means (nothing in the step waits for them) run there, behind an event; the
-    caller joins that stream before the results are read (the captured step: a stream the backward joins at its end)."""
+    caller joins that stream before the results are read (the captured step: a stream the backward joins at its end).
+    `split_out` (a zero-initialised ops.SplitTensor [B, D] with its shift set; wide tables): the two kernels write the
+    gradient there as split rows, the operand of the head's backward products, and no float32 gradient exists (the
+    third result is `split_out`): saves the 137 MB float32 image and its pack launch at the scale-sweep shape."""
     B, D = model_out.shape
     n = diffusion.num_numerical_features
     dev = model_out.device
-    # rows padded to 16 bytes (the pad columns are never read as data): float4 loads in the bias-gradient column sums
-    d_out = torch.empty((B, (D + 3) // 4 * 4), device=dev, dtype=torch.float32)[:, :D]
+    if split_out is not None:
+        if (split_out.rows, split_out.cols) != (B, D):
+            raise _lib.ClavaHipError("loss_and_grad: `split_out` has another shape")
+        d_out, d_num, d_cat, ld_d = split_out, None, None, 0
+    else:
+        # rows padded to 16 bytes (the pad columns are never read as data): float4 loads in the bias-gradient column sums
+        d_out = torch.empty((B, (D + 3) // 4 * 4), device=dev, dtype=torch.float32)[:, :D]
+        d_num, d_cat, ld_d = d_out, d_out[:, n:], d_out.stride(0)
+    sp = (ptr(split_out.buf), c_ll(split_out.pitch), c_int(split_out.shift)) if split_out is not None else (ptr(None), c_ll(0), c_int(0))
     ld_out = model_out.stride(0)                  # the wide-table head writes rows padded to 16 bytes
     loss_multi = loss_gauss = None
     if n > 0:
         if diffusion.gaussian_loss_type != "mse":
             raise NotImplementedError("gaussian_loss_type='kl' is not implemented on the HIP path (every config uses 'mse')")
         rows = torch.empty(B, device=dev, dtype=torch.float32)
-        check(lib().clava_gauss_mse_loss_f32(c_int(B), c_int(n), ptr(model_out), c_int(ld_out), ptr(noise), ptr(rows), ptr(d_out), c_int(d_out.stride(0)),
-                                             stream_ptr()), "clava_gauss_mse_loss_f32")
+        check(lib().clava_gauss_mse_loss_split_f32(c_int(B), c_int(n), ptr(model_out), c_int(ld_out), ptr(noise), ptr(rows), ptr(d_num), c_int(ld_d),
+                                                   *sp, ptr(overflow), stream_ptr()), "clava_gauss_mse_loss_split_f32")
         loss_gauss = _device_sum(rows, 1.0 / B, aux_stream)
     if diffusion.has_cat:
         if diffusion.multinomial_loss_type != "vb_stochastic" or diffusion.parametrization != "x0":
@@ -738,10 +766,10 @@ def loss_and_grad(diffusion, model_out, noise, idx0, idxt, t, aux_stream=None):
         terms = torch.empty((B, m), device=dev, dtype=torch.float32)
         sched = diffusion._c_schedule()
         pt = torch.tensor(1.0, dtype=torch.float32) / diffusion.num_timesteps        # ones_like(t).float() / T  (:592)
-        check(lib().clava_multinomial_loss_f32(ctypes.byref(sched), c_int(B), c_int(m), c_int(sk), ptr(diffusion._offsets_i32),
-                                               ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(ld_out), ptr(idx0), ptr(idxt), ptr(t),
-                                               c_float(float(pt)), ptr(terms), ptr(d_out[:, n:]), c_int(d_out.stride(0)), stream_ptr()),
-              "clava_multinomial_loss_f32")
+        check(lib().clava_multinomial_loss_split_f32(ctypes.byref(sched), c_int(B), c_int(m), c_int(sk), ptr(diffusion._offsets_i32),
+                                                     ptr(diffusion._log_k), ptr(model_out[:, n:]), c_int(ld_out), ptr(idx0), ptr(idxt), ptr(t),
+                                                     c_float(float(pt)), ptr(terms), ptr(d_cat), c_int(ld_d), *sp, c_int(n), ptr(overflow),
+                                                     stream_ptr()), "clava_multinomial_loss_split_f32")
         loss_multi = _device_sum(terms, 1.0 / (m * B), aux_stream)
     return loss_multi, loss_gauss, d_out
 

@@ -360,6 +360,19 @@ int clava_multinomial_loss_f32(const clava_schedule* sched, int B, int m, int su
                                const long long* t_rows, float pt, float* loss_terms, float* d_logits, int ld_d,
                                void* stream);
 
+/* The two loss kernels with the gradient ALSO (or, with d_out / d_logits null, ONLY) written as split rows -- the operand
+ * of the head's backward products (clava_gemm_f16x3, clava_gemm_wgrad_f16x3_tn) at scale 2^shift, 128 bytes per 32-column
+ * block as clava_split_pack_f32 writes them; `col0` = column of the first categorical column inside those rows (n_num).
+ * The same loss.backward() down to the denoiser output (scripts/train.py:37) without the float32 image and the pack
+ * launch between it and the products; columns the two kernels do not own (the pad beyond n_num + sumK) are left as they
+ * are (the caller zeroes the rows once).  *overflow is set to 1 when a scaled magnitude leaves the float16 range. */
+int clava_gauss_mse_loss_split_f32(int B, int n_num, const float* model_out, int ld_out, const float* noise, float* loss_rows,
+                                   float* d_out, int ld_d, void* d_split, long long pitch, int shift, int* overflow, void* stream);
+int clava_multinomial_loss_split_f32(const clava_schedule* sched, int B, int m, int sumK, const int* offsets, const float* log_k,
+                                     const float* logits, int ld_logits, const int* idx0, const int* idxt, const long long* t_rows,
+                                     float pt, float* loss_terms, float* d_logits, int ld_d, void* d_split, long long pitch, int shift,
+                                     int col0, int* overflow, void* stream);
+
 /* out[0] = scale * sum(v[0..n)), fixed summation order (the .mean() of the loss terms, :675). */
 int clava_sum_f32(const float* v, long long n, float scale, float* out, void* stream);
 

@@ -213,3 +213,36 @@ def test_narrow_product_from_split_rows_matches_float64(M, K, N):
     assert relerr(out, ref) < 2e-6
     tiled = ops.linear_f16x3(xs, wsp, b, out_f32=True, tile_config=7)
     assert relerr(out, tiled) < 2e-6
+
+
+@pytest.mark.parametrize("K,n_num,B", [([2, 3, 8, 9, 16, 17, 31, 33, 64, 65, 130, 257, 300, 1100], 5, 96), ([4, 7], 0, 33), ([40], 3, 7)])
+def test_loss_kernels_write_the_gradient_as_split_rows(K, n_num, B):
+    """clava_gauss_mse_loss_split_f32 / clava_multinomial_loss_split_f32: the split rows are byte-for-byte what
+    clava_split_pack_f32 makes of the float32 gradient (same scale, same two roundings), pad columns untouched (zero);
+    blocks of every lane-group width (8 / 16 / 32 lanes packed, 64 lanes in registers and streamed)."""
+    import numpy as np
+    from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+    sk = sum(K)
+    net = MLPDiffusion(n_num + sk, 0, "none", {"d_layers": [32, 32], "dropout": 0.0}).to(DEV)
+    d = GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=1000, device=torch.device(DEV)).to(DEV)
+    g = _gen(B)
+    x = torch.cat([torch.randn(B, n_num, device=DEV, generator=g)] +
+                  [torch.randint(0, k, (B, 1), device=DEV, generator=g).float() for k in K], 1)
+    word = torch.zeros(1, device=DEV, dtype=torch.int32)
+    t, noise, x_in, idx0, idxt = tr.draw_noised_input(d, x, 7, word, dense=False)
+    t[0] = 0                                                           # the decoder-NLL branch
+    out = torch.randn(B, n_num + sk, device=DEV, generator=g) * 3.0
+    lm, lg, d_out = tr.loss_and_grad(d, out, noise, idx0, idxt, t)
+    shift = 9
+    flag = ops.overflow_flag(DEV)
+    ds = ops.split_empty(B, n_num + sk, shift, DEV)
+    lm2, lg2, ret = tr.loss_and_grad(d, out, noise, idx0, idxt, t, split_out=ds, overflow=flag)
+    assert ret is ds
+    assert float(lm2) == float(lm) and (lg is None or float(lg2) == float(lg))
+    ref = ops.split_pack(d_out.contiguous(), shift, flag)
+    assert int(flag.item()) == 0
+    assert torch.equal(ds.buf, ref.buf)
+    # an overflowing scale raises the flag
+    big = ops.split_empty(B, n_num + sk, 60, DEV)
+    tr.loss_and_grad(d, out, noise, idx0, idxt, t, split_out=big, overflow=flag)
+    assert int(flag.item()) == 1
