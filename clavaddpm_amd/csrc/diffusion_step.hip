@@ -288,10 +288,28 @@ __global__ void __launch_bounds__(256) gauss_qsample_kernel(ScheduleDev s, int B
 // One training step's draws and the forward noising of the numeric columns in one launch: t ~ U{0..T-1} per row
 // (torch.randint of :590), noise ~ N(0, 1) (torch.randn_like of :647), x_t = gaussian_q_sample(x0, t, noise).  Draws are
 // keyed by (seed, step word, row / element): a captured step replays with fresh draws by advancing the device step word.
+//
+// Categorical columns (c.m > 0): x_t ~ q(x_t | x_0) per (row, feature) (q_sample, :494-498) drawn in CLOSED FORM.  The
+// reference perturbs the K log-probabilities q_pred(log one-hot(x_0), t) (:403-412) with Gumbel noise and takes the
+// arg-max (:506-516); those log-probabilities take two values -- lh for the clean class, lc for every other -- so the
+// arg-max is the clean class with probability p = e^lh / (e^lh + (K-1) e^lc) and otherwise uniform over the K-1 others:
+// the same distribution from two uniforms per block instead of K Gumbel draws (K logs and Philox words per block were
+// 107 us of the scale-sweep step's critical path; this is one thread per block).  lh, lc as the reference's float32
+// log_add_exp gives them.
+struct TrainDrawCat {
+    int m = 0;                          // categorical features (0: none)
+    const int* offsets = nullptr;       // [m + 1] class offsets
+    const float* log_k = nullptr;       // [m]
+    const float* x_cat = nullptr;       // clean class of feature f of row b = (int) x_cat[b * ldx + f]  (`x_cat.long()`, :650)
+    long long ldx = 0;
+    int* idx0 = nullptr;                // [B, m] clean classes
+    int* idxt = nullptr;                // [B, m] noised classes
+};
+
 __global__ void __launch_bounds__(256) train_draw_kernel(ScheduleDev s, int B, int n, const float* __restrict__ x0, long long ldx0,
                                                          unsigned long long seed, unsigned step_index,
                                                          const unsigned* __restrict__ step_counter, long long* __restrict__ t_out,
-                                                         float* __restrict__ noise, float* __restrict__ out, int ld_out) {
+                                                         float* __restrict__ noise, float* __restrict__ out, int ld_out, TrainDrawCat c) {
     const unsigned step_key = step_index + (step_counter ? *step_counter : 0u);
     const int per_row = n > 0 ? n : 1;
     const long long total = (long long)B * per_row;
@@ -307,6 +325,43 @@ __global__ void __launch_bounds__(256) train_draw_kernel(ScheduleDev s, int B, i
             out[(size_t)row * ld_out + col] = s.sqrt_alphas_cumprod[tt] * x0[(size_t)row * ldx0 + col] + s.sqrt_one_minus_alphas_cumprod[tt] * z;
         }
     }
+    const long long pairs = (long long)B * c.m;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / c.m), f = (int)(i - (long long)row * c.m);
+        const clava_rng::u4 rt = clava_rng::philox4x32_10(seed, (unsigned long long)row, step_key, clava_rng::STREAM_TRAIN_T);
+        const int tt = (int)(((unsigned long long)rt.x * (unsigned long long)s.T) >> 32);      // the row's t, as above
+        const int K = c.offsets[f + 1] - c.offsets[f];
+        const int hot = (int)c.x_cat[(size_t)row * c.ldx + f];
+        const float logk = c.log_k[f];
+        const float lca = s.log_cumprod_alpha[tt], uni = s.log_1_min_cumprod_alpha[tt] - logk;
+        const float lh = log_add_exp(0.f + lca, uni), lc = log_add_exp(LOG_TINY + lca, uni);
+        const clava_rng::u4 r = clava_rng::philox4x32_10(seed, (unsigned long long)i, step_key, clava_rng::STREAM_TRAIN_CAT);
+        int drawn;
+        if (hot < 0 || hot >= K) {
+            drawn = (int)(((unsigned long long)r.y * (unsigned long long)K) >> 32);            // no clean class: K equal log-probabilities
+        } else {
+            const float p_hot = 1.0f / (1.0f + (float)(K - 1) * exp_nonpos(fminf(lc - lh, 0.f)));
+            const int j = (int)(((unsigned long long)r.y * (unsigned long long)(K - 1)) >> 32);    // uniform on 0 .. K-2
+            drawn = (clava_rng::to_uniform(r.x) < p_hot || K < 2) ? hot : j + (j >= hot ? 1 : 0);
+        }
+        c.idx0[i] = hot;
+        c.idxt[i] = drawn;
+    }
+}
+
+// x_in[b, off_f + k] = 0 at k = idx[b, f], log(1e-30) elsewhere: index_to_log_onehot (tab_ddpm/utils.py:127-134) of the noised
+// classes for the dense first layer.  A thread owns one column (its feature found once by bisection) and walks the rows.
+__global__ void __launch_bounds__(256) cat_onehot_image_kernel(int B, int m, int sumK, const int* __restrict__ offsets,
+                                                               const int* __restrict__ idx, float* __restrict__ x_in, long long ld) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= sumK) return;
+    int lo = 0, hi = m - 1;                  // the feature f with offsets[f] <= col < offsets[f + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (offsets[mid] <= col) lo = mid; else hi = mid - 1;
+    }
+    const int k = col - offsets[lo];
+    for (int row = blockIdx.y; row < B; row += gridDim.y) x_in[(size_t)row * ld + col] = (idx[(size_t)row * m + lo] == k) ? 0.f : LOG_TINY;
 }
 
 // x_T ~ N(0, I): float32 normal draws (the reference draws torch.randn in float32, :1029) stored in the float64 state
@@ -459,8 +514,34 @@ int clava_train_draw_qsample_f32(const clava_schedule* sched, int B, int n_num, 
     const long long n = (long long)B * (n_num > 0 ? n_num : 1);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(train_draw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *sched, B, n_num, x0, ldx0, seed, step_index,
-                       step_counter, t_rows, noise, x_t, ld_xt);
+                       step_counter, t_rows, noise, x_t, ld_xt, TrainDrawCat());
     CLAVA_CHECK_LAUNCH("clava_train_draw_qsample_f32");
+    return CLAVA_OK;
+}
+
+int clava_train_draw_mixed_f32(const clava_schedule* sched, int B, int n_num, const float* x0, long long ldx0, int m, const int* offsets,
+                               const float* log_k, unsigned long long seed, unsigned step_index, const unsigned* step_counter,
+                               long long* t_rows, float* noise, float* x_t, int ld_xt, int* idx0, int* idxt, void* stream) {
+    CLAVA_CHECK_ARG(sched && t_rows && B > 0 && n_num >= 0 && m > 0 && sched->T > 0, "train_draw_mixed: bad arguments");
+    CLAVA_CHECK_ARG(x0 && offsets && log_k && idx0 && idxt && ldx0 >= (long long)n_num + m, "train_draw_mixed: categorical operands missing");
+    CLAVA_CHECK_ARG(n_num == 0 || (noise && x_t && ld_xt >= n_num), "train_draw_mixed: numeric operands missing");
+    long long n = (long long)B * (n_num > 0 ? n_num : 1);
+    if ((long long)B * m > n) n = (long long)B * m;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    TrainDrawCat c;
+    c.m = m; c.offsets = offsets; c.log_k = log_k; c.x_cat = x0 + n_num; c.ldx = ldx0; c.idx0 = idx0; c.idxt = idxt;
+    hipLaunchKernelGGL(train_draw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *sched, B, n_num, x0, ldx0, seed, step_index,
+                       step_counter, t_rows, noise, x_t, ld_xt, c);
+    CLAVA_CHECK_LAUNCH("clava_train_draw_mixed_f32");
+    return CLAVA_OK;
+}
+
+int clava_cat_onehot_image_f32(int B, int m, int sumK, const int* offsets, const int* idx, float* x_in, long long ld, void* stream) {
+    CLAVA_CHECK_ARG(B > 0 && m > 0 && sumK > 0 && offsets && idx && x_in && ld >= sumK, "cat_onehot_image: bad arguments");
+    const int gy = B < 512 ? B : 512;
+    hipLaunchKernelGGL(cat_onehot_image_kernel, dim3((sumK + 255) / 256, gy), dim3(256), 0, (hipStream_t)stream, B, m, sumK, offsets, idx,
+                       x_in, ld);
+    CLAVA_CHECK_LAUNCH("clava_cat_onehot_image_f32");
     return CLAVA_OK;
 }
 

@@ -8,7 +8,7 @@
 namespace clava_rng {
 
 enum : uint32_t { STREAM_GAUSS = 0, STREAM_CAT = 1, STREAM_INIT_GAUSS = 2, STREAM_INIT_CAT = 3, STREAM_TRAIN = 4, STREAM_TRAIN_T = 5,
-                  STREAM_TRAIN_NOISE = 6 };
+                  STREAM_TRAIN_NOISE = 6, STREAM_TRAIN_CAT = 7 };
 
 struct u4 { uint32_t x, y, z, w; };
 

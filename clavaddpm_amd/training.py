@@ -453,6 +453,7 @@ def denoiser_forward_split(net, x_in, t, st, cat=None):
 
 
 LOSS_SPLIT = os.environ.get("CLAVA_TRAIN_LOSS_SPLIT", "1") != "0"
+QSAMPLE_CLOSED = os.environ.get("CLAVA_TRAIN_QSAMPLE", "closed") != "gumbel"
 
 
 def loss_split_target(st, saved, model_out, splits=GRAD_SPLITS):
@@ -724,6 +725,21 @@ def draw_noised_input(diffusion, x, seed, step_counter, dense=True):
     noise = torch.empty((B, n), device=dev, dtype=torch.float32) if n > 0 else None
     xf = x if x.dtype == torch.float32 and x.stride(1) == 1 else x.float().contiguous()
     sched = diffusion._c_schedule()
+    if diffusion.has_cat and QSAMPLE_CLOSED:
+        # categorical q-sample in closed form inside the same launch (two uniforms per (row, feature) block instead of K
+        # Gumbel draws: the same distribution, see clava_train_draw_mixed_f32); CLAVA_TRAIN_QSAMPLE=gumbel keeps the
+        # per-class form
+        m, sk = diffusion._m, diffusion._sum_k
+        idx0 = torch.empty((B, m), device=dev, dtype=torch.int32)
+        idxt = torch.empty_like(idx0)
+        check(lib().clava_train_draw_mixed_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(xf), c_ll(xf.stride(0)), c_int(m),
+                                               ptr(diffusion._offsets_i32), ptr(diffusion._log_k), _lib.c_u64(seed), ctypes.c_uint(0),
+                                               ptr(step_counter), ptr(t), ptr(noise), ptr(x_in), c_int(D), ptr(idx0), ptr(idxt),
+                                               stream_ptr()), "clava_train_draw_mixed_f32")
+        if dense:
+            check(lib().clava_cat_onehot_image_f32(c_int(B), c_int(m), c_int(sk), ptr(diffusion._offsets_i32), ptr(idxt), ptr(x_in[:, n:]),
+                                                   c_ll(D), stream_ptr()), "clava_cat_onehot_image_f32")
+        return t, noise, x_in, idx0, idxt
     check(lib().clava_train_draw_qsample_f32(ctypes.byref(sched), c_int(B), c_int(n), ptr(xf), c_ll(xf.stride(0)), _lib.c_u64(seed),
                                              ctypes.c_uint(0), ptr(step_counter), ptr(t), ptr(noise), ptr(x_in), c_int(D),
                                              stream_ptr()), "clava_train_draw_qsample_f32")

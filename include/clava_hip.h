@@ -212,6 +212,20 @@ int clava_train_draw_qsample_f32(const clava_schedule* sched, int B, int n_num, 
                                  unsigned long long seed, unsigned step_index, const unsigned* step_counter, long long* t_rows,
                                  float* noise, float* x_t, int ld_xt, void* stream);
 
+/* The same launch for a table with categorical columns: x0 rows hold [n_num numeric | m class codes as floats] (the
+ * training loop's `x`, :644-652); also writes idx0[B,m] (`x_cat.long()`) and idxt[B,m], the classes of
+ * x_t ~ q(x_t | x_0) (q_sample, :494-498).  The draw is the reference's Gumbel arg-max over q_pred's K log-probabilities
+ * (:403-412, :506-516) in closed form: those take two values (the clean class / any other), so x_t is the clean class with
+ * probability e^lh / (e^lh + (K-1) e^lc) and uniform over the others otherwise -- the same distribution from two uniforms
+ * per (row, feature) instead of K.  clava_multinomial_step_counter_f32 (mode 2) remains the per-class Gumbel form. */
+int clava_train_draw_mixed_f32(const clava_schedule* sched, int B, int n_num, const float* x0, long long ldx0, int m, const int* offsets,
+                               const float* log_k, unsigned long long seed, unsigned step_index, const unsigned* step_counter,
+                               long long* t_rows, float* noise, float* x_t, int ld_xt, int* idx0, int* idxt, void* stream);
+
+/* x_in[b, offsets[f] + k] = 0 at k = idx[b,f], log(1e-30) elsewhere: index_to_log_onehot (tab_ddpm/utils.py:127-134) of
+ * class indices [B,m], the categorical columns of the denoiser input (row stride ld, in floats). */
+int clava_cat_onehot_image_f32(int B, int m, int sumK, const int* offsets, const int* idx, float* x_in, long long ld, void* stream);
+
 /* x[B,n_num] (float64) <- standard normal draws, generated in float32 like torch.randn of :1029 / :990, from the
  * counter-based generator keyed by (seed, row_offset + row, column). */
 int clava_gauss_init_f64(double* x, int B, int n_num, unsigned long long seed, unsigned long long row_offset,

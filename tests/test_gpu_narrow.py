@@ -233,7 +233,7 @@ def test_loss_kernels_write_the_gradient_as_split_rows(K, n_num, B):
     t[0] = 0                                                           # the decoder-NLL branch
     out = torch.randn(B, n_num + sk, device=DEV, generator=g) * 3.0
     lm, lg, d_out = tr.loss_and_grad(d, out, noise, idx0, idxt, t)
-    shift = 9
+    shift = 4
     flag = ops.overflow_flag(DEV)
     ds = ops.split_empty(B, n_num + sk, shift, DEV)
     lm2, lg2, ret = tr.loss_and_grad(d, out, noise, idx0, idxt, t, split_out=ds, overflow=flag)

@@ -308,6 +308,52 @@ def test_device_draws_of_the_captured_step():
     assert float((xin0 - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("form", ["closed", "gumbel"])
+def test_categorical_q_sample_of_the_training_draws_has_the_reference_distribution(form, monkeypatch):
+    """clava_train_draw_mixed_f32 draws x_t ~ q(x_t | x_0) of the categorical columns in closed form (clean class with
+    probability e^lh / (e^lh + (K-1) e^lc), else uniform over the others); the reference perturbs q_pred's K
+    log-probabilities with Gumbel noise and takes the arg-max (:403-412, :494-516).  Both forms must show the exact
+    probabilities cumprod_alpha_t + (1 - cumprod_alpha_t) / K (4.5-sigma bars, 2^18 rows, every t of an 8-step schedule
+    and every feature), uniform targets among the other classes, the clean classes as idx0, a log-one-hot image that is
+    exactly index_to_log_onehot(idxt) (utils.py:127-134), and draws that are a pure function of (seed, step word)."""
+    from clavaddpm_amd import training as tr
+    monkeypatch.setattr(tr, "QSAMPLE_CLOSED", form == "closed")
+    torch.manual_seed(0)
+    K, n, T, B = [2, 5, 13, 40, 300], 1, 8, 1 << 18
+    net = MLPDiffusion(n + sum(K), 0, "none", {"d_layers": [32, 32], "dropout": 0.0}).to(DEV)
+    d = GaussianMultinomialDiffusion(np.array(K), n, net, num_timesteps=T, device=torch.device(DEV)).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.cat([torch.randn(B, n, device=DEV, generator=g)] +
+                  [torch.randint(0, k, (B, 1), device=DEV, generator=g).float() for k in K], 1)
+    word = torch.zeros(1, device=DEV, dtype=torch.int32)
+    t, _, x_in, idx0, idxt = tr.draw_noised_input(d, x, 77, word, dense=True)
+    t_b, _, x_in_b, idx0_b, idxt_b = tr.draw_noised_input(d, x, 77, word, dense=False)
+    assert torch.equal(idxt, idxt_b) and torch.equal(t, t_b) and x_in_b.shape[1] == n
+    assert torch.equal(idx0.long(), x[:, n:].long())
+    off = np.concatenate([[0], np.cumsum(K)])
+    image = torch.full((B, sum(K)), float(np.float32(np.log(1e-30))), device=DEV)
+    image.scatter_(1, idxt.long() + torch.tensor(off[:-1], device=DEV)[None, :], 0.0)
+    assert torch.equal(x_in[:, n:], image)
+    word.add_(1)
+    _, _, _, _, idxt_next = tr.draw_noised_input(d, x, 77, word, dense=False)
+    assert float((idxt_next != idxt).any(dim=1).float().mean()) > 0.5
+    ca = d.log_cumprod_alpha.double().exp().cpu().numpy()
+    stay = (idxt == idx0).cpu().numpy()
+    tt = t.cpu().numpy()
+    for f, k in enumerate(K):
+        for tv in range(T):
+            rows = tt == tv
+            nrow = int(rows.sum())
+            p = ca[tv] + (1 - ca[tv]) / k
+            assert abs(stay[rows, f].mean() - p) < 4.5 * (p * (1 - p) / nrow) ** 0.5 + 1e-6, (form, k, tv)
+        if k > 2:
+            moved = ~stay[:, f]
+            shift = ((idxt[:, f] - idx0[:, f]) % k).cpu().numpy()[moved]          # 1 .. k-1, uniform
+            counts = np.bincount(shift, minlength=k)[1:].astype(np.float64)
+            e = moved.sum() / (k - 1)
+            assert ((counts - e) ** 2 / e).sum() < (k - 2) + 4.5 * (2 * (k - 2)) ** 0.5, (form, k)
+
+
 def test_numeric_table_graph_replays_draw_fresh_timesteps_and_noise():
     """The captured step of a numeric-only table: every replay advances the device step word and so draws new t and noise."""
     from clavaddpm_amd import split_nets
