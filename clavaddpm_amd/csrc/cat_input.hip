@@ -113,7 +113,54 @@ __global__ void __launch_bounds__(256) cat_input_kernel(CatInputArgs a) {
     if (amax > (0x477fe000u << 1) && a.overflow) *a.overflow = 1;
 }
 
+// The gather form's weight operands, rebuilt every training step (the optimizer moved the weights): wt[k][c] = w[c][k]
+// (rows = input columns, 512 contiguous bytes each) and, per 64-column tile, the float64 sums of its categorical columns
+// per output row; a second launch adds the tiles in order: bias[c] = b[c] + L * sum_k w[c][n_num + k].  Two launches for
+// what took seven framework kernels (transpose copy, slice sum in float64, scale, add, casts): 50 -> ~10 us on the
+// stream the first layer waits for.
+constexpr int WT_TILE = 64;
+__global__ void __launch_bounds__(256) cat_weights_kernel(const float* __restrict__ w, long long ldw, int D, int n_num,
+                                                          float* __restrict__ wt, double* __restrict__ partial) {
+    __shared__ float tile[128][WT_TILE + 1];
+    const int k0 = blockIdx.x * WT_TILE;
+    for (int i = threadIdx.x; i < 128 * WT_TILE; i += 256) {
+        const int c = i / WT_TILE, k = i - c * WT_TILE;
+        tile[c][k] = (k0 + k < D) ? w[(long long)c * ldw + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * WT_TILE; i += 256) {
+        const int k = i >> 7, c = i & 127;
+        if (k0 + k < D) wt[(long long)(k0 + k) * 128 + c] = tile[c][k];
+    }
+    if (threadIdx.x < 128) {
+        double acc = 0.0;
+        for (int k = 0; k < WT_TILE; ++k)
+            if (k0 + k >= n_num) acc += (double)tile[threadIdx.x][k];          // columns beyond D were staged as zeros
+        partial[(long long)blockIdx.x * 128 + threadIdx.x] = acc;
+    }
+}
+__global__ void __launch_bounds__(128) cat_bias_kernel(const double* __restrict__ partial, int tiles, const float* __restrict__ b,
+                                                       double log_tiny, float* __restrict__ bias) {
+    double acc = 0.0;
+    for (int t = 0; t < tiles; ++t) acc += partial[(long long)t * 128 + threadIdx.x];
+    bias[threadIdx.x] = (float)((double)b[threadIdx.x] + log_tiny * acc);
+}
+
 }  // namespace
+
+extern "C" int clava_cat_input_weights_tiles(int D) { return D > 0 ? (D + WT_TILE - 1) / WT_TILE : 0; }
+
+extern "C" int clava_cat_input_weights_f32(const float* w, long long ldw, int d1, int D, int n_num, const float* b, double log_tiny,
+                                           float* wt, double* partial, float* cat_bias, void* stream) {
+    CLAVA_CHECK_ARG(d1 == 128, "cat_input_weights: layer width %d not supported (built for 128, dim_t of every config)", d1);
+    CLAVA_CHECK_ARG(w && b && wt && partial && cat_bias && D > 0 && n_num >= 0 && n_num <= D && ldw >= D, "cat_input_weights: bad arguments");
+    const int tiles = (D + WT_TILE - 1) / WT_TILE;
+    hipLaunchKernelGGL(cat_weights_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, w, ldw, D, n_num, wt, partial);
+    CLAVA_CHECK_LAUNCH("clava_cat_input_weights_f32");
+    hipLaunchKernelGGL(cat_bias_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, partial, tiles, b, log_tiny, cat_bias);
+    CLAVA_CHECK_LAUNCH("clava_cat_input_weights_f32(bias)");
+    return CLAVA_OK;
+}
 
 extern "C" int clava_cat_input_f32(const float* xnum, int ld_x, const int* idx, int B, int n_num, int m, int d1, const int* offsets,
                                    const float* num_wt, const float* cat_wt, const float* cat_bias, const float* emb, long long ld_emb,

@@ -64,8 +64,13 @@ struct LBlock {
     float q1_hot, q1_cold;         // q_pred_one_timestep(x_t) of the noised / any other category
     float evt_hot, evt_cold;       // q_pred(x_0, t-1) (identity at t = 0) of the clean / any other category
     float klp_hot, klp_cold;       // prior-KL terms exp(lq) (lq + log K) of the clean / any other category
+    // log true posterior q(x_{t-1} | x_t, x_0) and its exponential: four values per block, by (is the clean class, is the
+    // noised class), normalised in closed form by loss_block_wave
+    // (lt, exp(lt)) of [hh, hc, ch, cc] in this wavefront's four LDS slots (eight more scalars would not fit the scalar
+    // registers: the kernel's arguments alone take sixty)
+    const float2* post;
     __device__ __forceinline__ float q1(int c) const { return c == hott ? q1_hot : q1_cold; }
-    __device__ __forceinline__ float un_true(int c) const { return (c == hot0 ? evt_hot : evt_cold) + q1(c); }
+    __device__ __forceinline__ float2 posterior(int c) const { return post[(c == hot0 ? 0 : 2) + (c == hott ? 0 : 1)]; }
     __device__ __forceinline__ float ev(float lstart) const {                  // q_pred(., t-1) or identity at t = 0
         return t == 0 ? lstart : log_add_exp_acc(lstart + lca_p, uni_p);
     }
@@ -106,27 +111,27 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
             if ((j == 0 || j * 64 < K) && lane + 64 * j < K) sm.add(v[j], b.mx);
         b.lsum = sm.log_total();
     }
-    // normalisers of the model and true posteriors (direct per-block log-sum-exp)
-    float mm = -INFINITY, mt = -INFINITY;
+    // normaliser of the model posterior (direct per-block log-sum-exp; the true posterior's is closed form, LBlock)
+    float mm = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (j == 0 || j * 64 < K) {
             const int c = lane + 64 * j;
             v[j] = (v[j] - b.mx) - b.lsum;                                       // predict_start
             e[j] = b.ev(v[j]);
-            if (c < K) { mm = fmaxf(mm, e[j] + b.q1(c)); mt = fmaxf(mt, b.un_true(c)); }
+            if (c < K) mm = fmaxf(mm, e[j] + b.q1(c));
         }
     }
-    mm = group_max<64>(mm); mt = group_max<64>(mt);
-    CountedSum sm_m, sm_t;
+    mm = group_max<64>(mm);
+    CountedSum sm_m;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (j == 0 || j * 64 < K) {
             const int c = lane + 64 * j;
-            if (c < K) { sm_m.add(e[j] + b.q1(c), mm); sm_t.add(b.un_true(c), mt); }
+            if (c < K) sm_m.add(e[j] + b.q1(c), mm);
         }
     }
-    const float lse_m = mm + sm_m.log_total(), lse_t = mt + sm_t.log_total();
+    const float lse_m = mm + sm_m.log_total();
     // loss terms: KL(true || model) (t > 0) or decoder NLL (t == 0) (:555-572), and the prior KL (:544-553)
     float W = 0.f, loss = 0.f, klp = 0.f;
 #pragma unroll
@@ -140,9 +145,9 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
                     w[j] = (c == b.hot0) ? 1.0f : 1e-30f;                        // exp(log_x_start)
                     loss -= w[j] * lm;
                 } else {
-                    const float lt = b.un_true(c) - lse_t;
-                    w[j] = exp_nonpos(lt);
-                    loss += w[j] * (lt - lm);
+                    const float2 p = b.posterior(c);
+                    w[j] = p.y;
+                    loss += p.y * (p.x - lm);
                 }
                 W += w[j];
                 klp += (c == b.hot0) ? b.klp_hot : b.klp_cold;
@@ -193,18 +198,18 @@ __device__ __forceinline__ void loss_block_streamed(const MLossArgs& a, LBlock& 
     }
     auto lp = [&](int c) { return (b.lg[c] - b.mx) - b.lsum; };
     auto un_model = [&](int c) { return b.ev(lp(c)) + b.q1(c); };
-    float mm = -INFINITY, mt = -INFINITY;
-    for (int c = lane; c < K; c += 64) { mm = fmaxf(mm, un_model(c)); mt = fmaxf(mt, b.un_true(c)); }
-    mm = group_max<64>(mm); mt = group_max<64>(mt);
-    CountedSum sm_m, sm_t;
-    for (int c = lane; c < K; c += 64) { sm_m.add(un_model(c), mm); sm_t.add(b.un_true(c), mt); }
-    const float lse_m = mm + sm_m.log_total(), lse_t = mt + sm_t.log_total();
-    auto weight = [&](int c) { return (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : exp_nonpos(b.un_true(c) - lse_t); };
+    float mm = -INFINITY;
+    for (int c = lane; c < K; c += 64) mm = fmaxf(mm, un_model(c));
+    mm = group_max<64>(mm);
+    CountedSum sm_m;
+    for (int c = lane; c < K; c += 64) sm_m.add(un_model(c), mm);
+    const float lse_m = mm + sm_m.log_total();
+    auto weight = [&](int c) { return (b.t == 0) ? ((c == b.hot0) ? 1.0f : 1e-30f) : b.posterior(c).y; };
     float W = 0.f, loss = 0.f, klp = 0.f;
     for (int c = lane; c < K; c += 64) {
         const float lm = un_model(c) - lse_m, w = weight(c);
         if (b.t == 0) loss -= w * lm;
-        else loss += w * ((b.un_true(c) - lse_t) - lm);
+        else loss += w * (b.posterior(c).x - lm);
         W += w;
         klp += (c == b.hot0) ? b.klp_hot : b.klp_cold;
     }
@@ -293,7 +298,7 @@ __device__ __forceinline__ void loss_block_packed(const MLossArgs& a, const RowS
 }
 
 // One (row, feature) block per wavefront: per-block quantities in scalar registers.
-__device__ __forceinline__ void loss_block_wave(const MLossArgs& a, const RowScalars& r, int row, int f, int lane) {
+__device__ __forceinline__ void loss_block_wave(const MLossArgs& a, const RowScalars& r, int row, int f, int lane, float2* post) {
     const size_t pair = (size_t)row * a.m + f;
     const int o = __builtin_amdgcn_readfirstlane(a.offsets[f]);
     LBlock b;
@@ -326,6 +331,28 @@ __device__ __forceinline__ void loss_block_wave(const MLossArgs& a, const RowSca
         b.evt_cold = b.t == 0 ? LOG_TINY : rl(lae, 3);
         b.klp_hot = rl(kl, 4);
         b.klp_cold = rl(kl, 5);
+        // True posterior (:555-566 via q_posterior, :426-452): its un-normalised logarithm (c == clean ? evt_hot : evt_cold)
+        // + q1(c) takes four values -- lane j < 4 holds value j of [hh, hc, ch, cc] -- carried by (1 | 0, 1 | 0, 1 | 0, the
+        // rest) of the K classes, so the normaliser is a four-term counted log-sum-exp instead of a pass over the classes
+        // (two exponentials per class before), and exp(lt) one evaluation for the four values.
+        const int jj = lane & 3;
+        const float un = ((jj < 2) ? b.evt_hot : b.evt_cold) + ((jj & 1) ? b.q1_cold : b.q1_hot);
+        const bool in0 = b.hot0 >= 0 && b.hot0 < b.K, int_ = b.hott >= 0 && b.hott < b.K;
+        const bool same = in0 && b.hot0 == b.hott;
+        const int n_hh = same ? 1 : 0, n_hc = (in0 && !same) ? 1 : 0, n_ch = (int_ && !same) ? 1 : 0;
+        const int cnt_i = jj == 0 ? n_hh : jj == 1 ? n_hc : jj == 2 ? n_ch : b.K - n_hh - n_hc - n_ch;
+        const float cnt = (float)cnt_i;
+        const float um = cnt_i > 0 ? un : -INFINITY;
+        const float mt = fmaxf(fmaxf(rl(um, 0), rl(um, 1)), fmaxf(rl(um, 2), rl(um, 3)));
+        const float d = um - mt;                                  // -inf for an absent value: contributes exp(-inf) * 0
+        const float at_max = (cnt_i > 0 && d == 0.f) ? cnt : 0.f;
+        const float below = (cnt_i > 0 && d != 0.f) ? cnt * exp_nonpos(d) : 0.f;
+        const float n_max = (rl(at_max, 0) + rl(at_max, 1)) + (rl(at_max, 2) + rl(at_max, 3));
+        const float rest = (rl(below, 0) + rl(below, 1)) + (rl(below, 2) + rl(below, 3));
+        const float lse_t = mt + log_sum_counted(n_max, rest);
+        const float ltj = un - lse_t;
+        if (lane < 4) post[lane] = make_float2(ltj, exp_nonpos(ltj));       // read back by this wavefront only: LDS keeps its order
+        b.post = post;
     }
     if (b.K <= 256) loss_block_cached<4>(a, b, lane, pair);
     else if (b.K <= 1024) loss_block_cached<16>(a, b, lane, pair);
@@ -349,7 +376,7 @@ __device__ __forceinline__ RowScalars row_scalars(const MLossArgs& a, int row, f
 // row per wavefront work item.
 template <int G>
 __device__ __forceinline__ void loss_bucket(const MLossArgs& a, const int* s_off, const float* s_logk, const int* perm, int n_feat,
-                                            long long wave0, long long n_waves) {
+                                            long long wave0, long long n_waves, float2* post) {
     constexpr int PER = 64 / G;
     const int W = (n_feat + PER - 1) / PER;                 // work items per row
     if (W == 0) return;
@@ -367,7 +394,7 @@ __device__ __forceinline__ void loss_bucket(const MLossArgs& a, const int* s_off
         if (w >= W) { w -= W; ++row; if (row >= a.B) break; }
         const RowScalars r = row_scalars(a, row, lca_T, l1mca_T);
         if (G == 64) {
-            loss_block_wave(a, r, row, perm ? perm[w] : w, lane);
+            loss_block_wave(a, r, row, perm ? perm[w] : w, lane, post);
         } else {
             const int fi = w * PER + sub;
             const int f = perm[min(fi, n_feat - 1)];        // a group beyond the bucket repeats its last feature and stores nothing
@@ -382,10 +409,12 @@ __global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
     __shared__ float s_logk[MAX_LDS_FEATURES];
     __shared__ int s_perm[MAX_LDS_FEATURES];
     __shared__ int s_start[5];
+    __shared__ float2 s_post[4][4];                     // per wavefront: the true posterior's four values (LBlock::post)
+    float2* post = s_post[threadIdx.x >> 6];
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
     if (a.m > MAX_LDS_FEATURES || !a.pack) {            // more features than the LDS tables hold: one wavefront per block
-        loss_bucket<64>(a, nullptr, nullptr, nullptr, a.m, wave0, n_waves);
+        loss_bucket<64>(a, nullptr, nullptr, nullptr, a.m, wave0, n_waves, post);
         return;
     }
     for (int i = threadIdx.x; i <= a.m; i += blockDim.x) s_off[i] = a.offsets[i];
@@ -394,10 +423,10 @@ __global__ void __launch_bounds__(256) multinomial_loss_kernel(MLossArgs a) {
     order_features_by_width(a.m, s_off, s_perm, s_start);
     const int st1 = s_start[1], st2 = s_start[2], st3 = s_start[3];
     // one loop per width (a single loop over mixed items would keep every variant's registers live at once)
-    loss_bucket<8>(a, s_off, s_logk, s_perm, st1, wave0, n_waves);
-    loss_bucket<16>(a, s_off, s_logk, s_perm + st1, st2 - st1, wave0, n_waves);
-    loss_bucket<32>(a, s_off, s_logk, s_perm + st2, st3 - st2, wave0, n_waves);
-    loss_bucket<64>(a, s_off, s_logk, s_perm + st3, a.m - st3, wave0, n_waves);
+    loss_bucket<8>(a, s_off, s_logk, s_perm, st1, wave0, n_waves, post);
+    loss_bucket<16>(a, s_off, s_logk, s_perm + st1, st2 - st1, wave0, n_waves, post);
+    loss_bucket<32>(a, s_off, s_logk, s_perm + st2, st3 - st2, wave0, n_waves, post);
+    loss_bucket<64>(a, s_off, s_logk, s_perm + st3, a.m - st3, wave0, n_waves, post);
 }
 
 // ---------------------------------------------------------------------------------------------- reductions

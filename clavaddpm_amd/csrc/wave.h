@@ -77,7 +77,7 @@ __device__ __forceinline__ float log_pos(float x) {
 // odd series (five terms, truncation < 1e-10 relative at z <= 1/9); above: the plain logarithm (result >= 0.22).
 __device__ __forceinline__ float log1p_acc(float x) {
     if (x > 0.25f) return log_pos(1.0f + x);
-    const float z = x / (2.0f + x), z2 = z * z;
+    const float z = x * __builtin_amdgcn_rcpf(2.0f + x), z2 = z * z;       // 1-ulp reciprocal: the series needs ~1e-7
     float p = __builtin_fmaf(z2, 1.0f / 9.0f, 1.0f / 7.0f);
     p = __builtin_fmaf(z2, p, 0.2f);
     p = __builtin_fmaf(z2, p, 1.0f / 3.0f);

@@ -273,7 +273,13 @@ class SplitTrainState:
         if getattr(self, "_wt0", None) is None or self._wt0.shape[0] != D:
             self._wt0 = torch.empty((D, w0.shape[0]), device=w0.device, dtype=torch.float32)
             self._cat_bias = torch.empty(w0.shape[0], device=w0.device, dtype=torch.float32)
+            self._cat_partial = torch.empty(lib().clava_cat_input_weights_tiles(c_int(D)) * 128, device=w0.device, dtype=torch.float64)
         log_tiny = float(torch.log(torch.tensor(1e-30, dtype=torch.float32)))
+        if w0.shape[0] == 128 and w0.stride(1) == 1:
+            check(lib().clava_cat_input_weights_f32(ptr(w0), c_ll(w0.stride(0)), c_int(128), c_int(D), c_int(n_num), ptr(b0),
+                                                    ctypes.c_double(log_tiny), ptr(self._wt0), ptr(self._cat_partial), ptr(self._cat_bias),
+                                                    stream_ptr()), "clava_cat_input_weights_f32")
+            return
         self._wt0.copy_(w0.t())
         self._cat_bias.copy_(b0.double() + log_tiny * w0[:, n_num:].sum(dim=1, dtype=torch.float64))
 
@@ -291,9 +297,11 @@ class SplitTrainState:
         fork.record(main)
         with torch.cuda.stream(side):
             side.wait_event(fork)
-            self.pack_weights(ws, self.wide(d_in), dev, gather=gather_n_num is not None)   # every weight operand of this step's products
-            if gather_n_num is not None:
+            if gather_n_num is not None:             # first: the first layer is the first consumer
                 self.gather_weights(ws[0].detach(), net.stack()[1][0].detach(), gather_n_num)
+                self._gathered = torch.cuda.Event()
+                self._gathered.record(side)
+            self.pack_weights(ws, self.wide(d_in), dev, gather=gather_n_num is not None)   # every weight operand of this step's products
             self._packed = torch.cuda.Event()
             self._packed.record(side)
 
@@ -380,7 +388,7 @@ def denoiser_forward_split(net, x_in, t, st, cat=None):
         check(lib().clava_train_front_f32(ptr(t.contiguous()), c_int(B), ptr(_freqs(128, dev)), c_int(128), None, c_ll(0), c_int(0),
                                           ptr(w0), ptr(b0), ptr(w2), ptr(b2), None, None, ptr(te), ptr(z1), ptr(a1), ptr(emb), None,
                                           c_ll(0), c_int(0), None, stream_ptr()), "clava_train_front_f32(emb)")
-        main.wait_event(packed)                   # the transposed weight and the folded bias come from the packing stream
+        main.wait_event(st._gathered)             # the transposed weight and the folded bias come from the packing stream
         h = None if planes_only else torch.empty((B, 128), device=dev, dtype=torch.float32)
         hsp = st.buf(("h", 0), B, 128, dev)
         hsp.shift = st.shift_h[0]
@@ -388,6 +396,7 @@ def denoiser_forward_split(net, x_in, t, st, cat=None):
                                         ptr(diffusion._offsets_i32), ptr(st._wt0), ptr(st._wt0[n_num:]), ptr(st._cat_bias), ptr(emb),
                                         c_ll(128), c_float(gp["log_tiny"]), c_int(0), ptr(hsp.buf), c_ll(hsp.pitch), c_int(hsp.shift),
                                         ptr(h), c_ll(128), ptr(st.flag), stream_ptr()), "clava_cat_input_f32")
+        main.wait_event(packed)                   # the other layers' operands
         hs = [h]
         hsplit = [hsp]
         catinfo = (idx, diffusion, gp)

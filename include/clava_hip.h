@@ -476,6 +476,13 @@ int clava_cat_input_f32(const float* xnum, int ld_x, const int* idx, int B, int 
                         const float* num_wt, const float* cat_wt, const float* cat_bias, const float* emb, long long ld_emb,
                         float log_tiny, int act, void* out_split, long long pitch, int shift, float* out_f32, long long ld_f32,
                         int* overflow, void* stream);
+
+/* The weight operands of clava_cat_input_f32 from proj's parameters (training: rebuilt every step): wt[D][128] = w^T and
+ * cat_bias[c] = b[c] + log_tiny * sum_{k >= n_num} w[c][k] (float64 sums in a fixed order).  `partial` is scratch of
+ * clava_cat_input_weights_tiles(D) * 128 doubles. */
+int clava_cat_input_weights_tiles(int D);
+int clava_cat_input_weights_f32(const float* w, long long ldw, int d1, int D, int n_num, const float* b, double log_tiny,
+                                float* wt, double* partial, float* cat_bias, void* stream);
 int clava_cat_wgrad_workgroups(const int* offsets_host, int m);
 int clava_cat_wgrad_plan(const int* offsets_host, int m, int* wg_feature_host, int* wg_k0_host);
 int clava_cat_wgrad_f32(const float* g, long long ldg, const float* g_colsum_slabs, int B, int d1, const int* idx, int m,

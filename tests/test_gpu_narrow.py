@@ -246,3 +246,18 @@ def test_loss_kernels_write_the_gradient_as_split_rows(K, n_num, B):
     big = ops.split_empty(B, n_num + sk, 60, DEV)
     tr.loss_and_grad(d, out, noise, idx0, idxt, t, split_out=big, overflow=flag)
     assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("D,n_num", [(8397, 100), (130, 0), (64, 64), (77, 5)])
+def test_gather_form_weight_operands_match_torch(D, n_num):
+    """clava_cat_input_weights_f32: proj's weight transposed exactly, and b + log(1e-30) * (float64 row sums of the
+    categorical columns) rounded to float32 (the constant part of the log-one-hot columns, tab_ddpm/utils.py:127-134)."""
+    g = _gen(D)
+    w = torch.randn(128, D + 3, device=DEV, generator=g)[:, :D]
+    b = torch.randn(128, device=DEV, generator=g)
+    st = tr.SplitTrainState()
+    st.gather_weights(w, b, n_num)
+    log_tiny = float(torch.log(torch.tensor(1e-30, dtype=torch.float32)))
+    assert torch.equal(st._wt0, w.t().contiguous())
+    ref = b.double() + log_tiny * w[:, n_num:].double().sum(dim=1)
+    assert float((st._cat_bias.double() - ref).abs().max()) <= 1e-7 * float(ref.abs().max())
