@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CLAVA_HIP_VERSION 109
+#define CLAVA_HIP_VERSION 110
 
 /* activation codes */
 #define CLAVA_ACT_NONE_ 0

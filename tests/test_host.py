@@ -19,7 +19,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), n
-    assert L.clava_version() == 109
+    assert L.clava_version() == 110
     assert L.clava_device_count() >= 0            # host-only probe; no compute call without a GPU
 
 
