@@ -354,6 +354,25 @@ def test_categorical_q_sample_of_the_training_draws_has_the_reference_distributi
             assert ((counts - e) ** 2 / e).sum() < (k - 2) + 4.5 * (2 * (k - 2)) ** 0.5, (form, k)
 
 
+def test_closed_form_q_sample_edge_cases():
+    """A one-class feature can only stay where it is; a clean class outside its feature (corrupt input) has no clean class
+    to favour and draws uniformly inside the feature -- never an index outside it (the gather-form first layer and the
+    class-sum weight gradient index with it)."""
+    from clavaddpm_amd import training as tr
+    torch.manual_seed(0)
+    K, B = [1, 6], 1 << 14
+    net = MLPDiffusion(sum(K), 0, "none", {"d_layers": [32, 32], "dropout": 0.0}).to(DEV)
+    d = GaussianMultinomialDiffusion(np.array(K), 0, net, num_timesteps=10, device=torch.device(DEV)).to(DEV)
+    x = torch.zeros(B, 2, device=DEV)
+    x[:, 1] = 9.0                                           # outside 0..5
+    word = torch.zeros(1, device=DEV, dtype=torch.int32)
+    t, noise, x_in, idx0, idxt = tr.draw_noised_input(d, x, 3, word, dense=False)
+    assert noise is None and int(idxt[:, 0].abs().max()) == 0
+    assert int(idxt[:, 1].min()) == 0 and int(idxt[:, 1].max()) == 5
+    counts = torch.bincount(idxt[:, 1].long(), minlength=6).double()
+    assert float(((counts - B / 6) ** 2 / (B / 6)).sum()) < 5 + 4.5 * 10 ** 0.5
+
+
 def test_numeric_table_graph_replays_draw_fresh_timesteps_and_noise():
     """The captured step of a numeric-only table: every replay advances the device step word and so draws new t and noise."""
     from clavaddpm_amd import split_nets
