@@ -289,12 +289,15 @@ bool classifier_fusable(const clava_chain* c, const clava_split_net* k) {
 }
 
 inline long long align256(long long v) { return (v + 255) / 256 * 256; }
+// rows of the denoiser output padded to whole float4s: the head's epilogue then stores 16 bytes per lane (with an odd row
+// stride -- 8397 columns at the scale-sweep shape -- it fell back to 4-byte stores: 183 us against 105 for that product)
+inline int model_out_ld(int D) { return (D + 3) & ~3; }
 
 struct SplitChainWs {
     float* x_in;        // [B, D] float32 denoiser input (written by the step kernels)
     char* x_split;      // the same as split rows
     char* den[2];       // ping-pong hidden activations
-    float* model_out;   // [B, D]
+    float* model_out;   // [B, model_out_ld(D)]
     char* cls_out[64];  // classifier activations, kept for the backward pass
     float* logits;      // [B, C]
     char* dlogits;      // split rows [B, C]
@@ -312,7 +315,7 @@ void carve_split(const clava_chain* c, const clava_split_net* d, const clava_spl
     const int hw = max_width_dims(d->dims, 1, d->n_layers - 1);
     w.den[0] = take(B * split_pitch(hw));
     w.den[1] = take(B * split_pitch(hw));
-    w.model_out = (float*)take(4LL * B * D);
+    w.model_out = (float*)take(4LL * B * model_out_ld(D));
     w.logits = nullptr; w.dlogits = nullptr; w.gx = nullptr; w.cls_grad[0] = w.cls_grad[1] = nullptr;
     if (k) {
         for (int l = 0; l + 1 < k->n_layers; ++l) w.cls_out[l] = take(B * split_pitch(k->dims[l + 1]));
@@ -626,7 +629,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                                const SplitChainWs& w, int* overflow, hipStream_t caller, StreamPool* pool, int n_groups, bool side,
                                ChainGroup* groups, int& ng) {
     int rc = CLAVA_OK;
-    const int D = d->dims[0], nd = d->n_layers;
+    const int D = d->dims[0], nd = d->n_layers, ldm = model_out_ld(D);
     const int emb_w = d->dims[1];
     const int rows_per = ((B + n_groups - 1) / n_groups + 63) / 64 * 64;     // whole 64-row blocks per group
     // tables with categorical columns and no guidance network: the first layer gathers m weight columns per row
@@ -669,7 +672,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             const int r0 = G.r0, R = G.rows;
             float* x_in = w.x_in + (size_t)r0 * D;
             char* x_split = rowp(w.x_split, split_pitch(D), r0);
-            float* model_out = w.model_out + (size_t)r0 * D;
+            float* model_out = w.model_out + (size_t)r0 * ldm;
             // ---- denoiser input as split rows: packed from the float32 image once; afterwards the step kernels write the
             // next input's planes themselves (pad columns keep the zeros of this first pack)
             if (s == 0 && !cat_gather) {
@@ -713,10 +716,10 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 ca.overflow = overflow;
                 rc = clava_launch_cat_input(ca, G.den);
                 if (rc) return rc;
-                rc = split_net_forward(d, outs[0], R, nullptr, outs, model_out, D, overflow, G.den, 1);
+                rc = split_net_forward(d, outs[0], R, nullptr, outs, model_out, ldm, overflow, G.den, 1);
                 if (rc) return rc;
             } else {
-                rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, D, overflow, G.den);
+                rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, ldm, overflow, G.den);
                 if (rc) return rc;
             }
             // ---- guidance: grad_x log p(y | x_t), on the group's second stream
@@ -803,7 +806,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             if (c->n_num > 0) {
                 GaussStepArgs g;
                 g.s = c->sched; g.B = R; g.n_num = c->n_num;
-                g.eps = model_out; g.ld_eps = D;
+                g.eps = model_out; g.ld_eps = ldm;
                 g.x = x + (size_t)r0 * c->n_num;
                 g.grad = grad; g.ld_grad = c->n_num;
                 g.noise = c->noise ? c->noise + ((size_t)s * B + r0) * c->n_num : nullptr;
@@ -836,7 +839,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             if (c->m > 0) {
                 MultiStepArgs q;
                 q.s = c->sched; q.B = R; q.m = c->m; q.sumK = c->sumK; q.mode = MULTI_MODE_REVERSE;
-                q.logits = model_out + c->n_num; q.ld_logits = D;
+                q.logits = model_out + c->n_num; q.ld_logits = ldm;
                 q.idx_in = idx + (size_t)r0 * c->m; q.idx_out = idx + (size_t)r0 * c->m;
                 q.uniforms = c->uniforms ? c->uniforms + ((size_t)s * B + r0) * c->sumK : nullptr; q.ld_u = c->sumK;
                 q.x_in = nullptr; q.ld_xin = 0;
