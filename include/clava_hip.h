@@ -477,7 +477,8 @@ int clava_cat_input_f32(const float* xnum, int ld_x, const int* idx, int B, int 
                         float log_tiny, int act, void* out_split, long long pitch, int shift, float* out_f32, long long ld_f32,
                         int* overflow, void* stream);
 
-/* The weight operands of clava_cat_input_f32 from proj's parameters (training: rebuilt every step): wt[D][128] = w^T and
+/* The weight operands of clava_cat_input_f32 from the parameters of MLPDiffusion.proj (tab_ddpm/modules.py:444, applied at
+ * :459; training: rebuilt every step, after scripts/train.py:38 moved them): wt[D][128] = w^T and
  * cat_bias[c] = b[c] + log_tiny * sum_{k >= n_num} w[c][k] (float64 sums in a fixed order).  `partial` is scratch of
  * clava_cat_input_weights_tiles(D) * 128 doubles. */
 int clava_cat_input_weights_tiles(int D);
