@@ -47,7 +47,7 @@ def _blocks(clf):
     return out, j, mods[j]
 
 
-def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=True):
+def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=True, count=True):
     B, C = a.shape
     dev = a.device
     mean = torch.empty(C, device=dev, dtype=torch.float32)
@@ -59,7 +59,7 @@ def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=
                                            c_float(bn.eps), c_float(p), ptr(keep), c_int(keep.stride(0) if keep is not None else 0),
                                            c_u64(seed), c_u32(step), ptr(step_dev), c_u32(layer), ptr(ws), ptr(mean), ptr(invstd),
                                            ptr(h), c_int(h.stride(0)), stream_ptr()), "clava_bn_dropout_train_f32")
-    if update_running:
+    if update_running and count:
         bn.num_batches_tracked += 1
     return h, mean, invstd
 
@@ -67,23 +67,38 @@ def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=
 def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=None):
     """Train-mode `Classifier.forward` keeping what the backward needs.  `keeps`: per-block uint8 [B, C_i] Dropout keep
     masks (parity tests) or None for the in-kernel generator keyed by (seed, step or *step_dev, block)."""
-    te = timestep_embedding(t, clf.dim_t)
     w0, b0 = clf.time_embed[0].weight.detach(), clf.time_embed[0].bias.detach()
     w2, b2 = clf.time_embed[2].weight.detach(), clf.time_embed[2].bias.detach()
-    z1 = ops.linear(te, w0, b0)
-    a1 = _tr._silu(z1)
-    emb = ops.linear(a1, w2, b2)
-    h = ops.linear(x_t, clf.proj.weight.detach(), clf.proj.bias.detach(), rowadd=emb)
+    B = x_t.shape[0]
+    dev = x_t.device
+    if _tr.FRONT_FUSED and clf.dim_t == 128 and t.dtype == torch.int64 and x_t.dtype == torch.float32 and x_t.stride(1) == 1:
+        # timestep embedding, time MLP and proj(x) + emb in one launch (csrc/train_front.hip: five launches otherwise, each
+        # with a dependent-launch gap on the step's one critical chain)
+        from .tab_ddpm.modules import _freqs
+        te, z1, a1, h = (torch.empty((B, 128), device=dev, dtype=torch.float32) for _ in range(4))
+        check(lib().clava_train_front_f32(ptr(t.contiguous()), c_int(B), ptr(_freqs(128, dev)), c_int(128), ptr(x_t), c_ll(x_t.stride(0)),
+                                          c_int(x_t.shape[1]), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(clf.proj.weight.detach()),
+                                          ptr(clf.proj.bias.detach()), ptr(te), ptr(z1), ptr(a1), ptr(h), None, c_ll(0), c_int(0), None,
+                                          stream_ptr()), "clava_train_front_f32")
+    else:
+        te = timestep_embedding(t, clf.dim_t)
+        z1 = ops.linear(te, w0, b0)
+        a1 = _tr._silu(z1)
+        emb = ops.linear(a1, w2, b2)
+        h = ops.linear(x_t, clf.proj.weight.detach(), clf.proj.bias.detach(), rowadd=emb)
     blocks, _, head = _blocks(clf)
     ws = _bn_workspace(max(b[1].out_features for b in blocks), x_t.device)
     hs, acts, stats = [h], [], []
     for i, (j, lin, act, slope, bn, p) in enumerate(blocks):
         a = ops.linear(hs[-1], lin.weight.detach(), lin.bias.detach(), act="relu" if act == ACT_RELU else "leaky_relu")
         keep = keeps[i] if keeps is not None else None
-        h, mean, invstd = _bn_dropout(a, bn, p, keep, seed, step, step_dev, i, ws)
+        h, mean, invstd = _bn_dropout(a, bn, p, keep, seed, step, step_dev, i, ws, count=False)
         acts.append(a)
         stats.append((mean, invstd))
         hs.append(h)
+    # `num_batches_tracked += 1` of every BatchNorm (torch's train-mode forward) as ONE multi-tensor launch instead of one
+    # tiny kernel per layer on the critical chain
+    torch._foreach_add_([b[4].num_batches_tracked for b in blocks], 1)
     logits = ops.linear(hs[-1], head.weight.detach(), head.bias.detach())
     return logits, (x_t, te, z1, a1, hs, acts, stats)
 
@@ -160,8 +175,13 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
     g = dh                                             # gradient w.r.t. proj(x) + emb
     param_grads("proj", g, x_t)
     param_grads("time_embed.2", g, a1)
-    d_a1 = ops.linear_dgrad(g, clf.time_embed[2].weight.detach())
-    d_z1 = _tr._silu_backward(z1, d_a1)
+    if _tr.FRONT_FUSED and clf.dim_t == 128 and g.stride(1) == 1:
+        d_z1 = torch.empty_like(z1)               # input gradient of time_embed[2] and SiLU' in one launch
+        check(lib().clava_train_time_bwd_f32(ptr(g), c_ll(g.stride(0)), c_int(B), c_int(128), ptr(clf.time_embed[2].weight.detach()),
+                                             ptr(z1), ptr(d_z1), stream_ptr()), "clava_train_time_bwd_f32")
+    else:
+        d_a1 = ops.linear_dgrad(g, clf.time_embed[2].weight.detach())
+        d_z1 = _tr._silu_backward(z1, d_a1)
     param_grads("time_embed.0", d_z1, te)
     if side is not None:
         done = torch.cuda.Event()
@@ -303,11 +323,12 @@ class ClassifierTrainer:
         B = x_t.shape[0]
         logits, saved = classifier_forward_train(clf, x_t, t, keeps, self.seed, 0, self.step_dev)
         rows, lse, acc1, acc5 = cross_entropy(logits, labels)
-        loss = _tr._device_sum(rows, 1.0 / B)
-        a1 = _tr._device_sum(acc1, 1.0 / B)
-        a5 = _tr._device_sum(acc5, 1.0 / B) if acc5 is not None else None
         if self._side is None and os.environ.get("CLAVA_TRAIN_STREAMS", "2") != "1":
             self._side = torch.cuda.Stream(device=self.device)
+        loss = _tr._device_sum(rows, 1.0 / B)          # the backward starts from it (`loss.backward(loss)`, :700)
+        # the two accuracies are only reported: summed on the weight-gradient stream, which the backward joins at its end
+        a1 = _tr._device_sum(acc1, 1.0 / B, self._side)
+        a5 = _tr._device_sum(acc5, 1.0 / B, self._side) if acc5 is not None else None
         self._keep = classifier_backward(clf, saved, logits, labels, lse, loss, self.layout, self.slabs, keeps, self.seed, 0,
                                          self.step_dev, side=self._side)
         self.step_dev += 1
