@@ -123,33 +123,46 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
         }
     }
     mm = group_max<64>(mm);
-    CountedSum sm_m;
+    // w[j] keeps exp(un_model - mm) of the class (exactly 1 at the maximum) until the backward pass, where it gives the
+    // model posterior exp(lm) = w[j] / total without a second exponential
+    float tot_m;
+    float lse_m;
+    {
+        float n_max = 0.f, rest = 0.f;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        if (j == 0 || j * 64 < K) {
-            const int c = lane + 64 * j;
-            if (c < K) sm_m.add(e[j] + b.q1(c), mm);
+        for (int j = 0; j < NCH; ++j) {
+            if (j == 0 || j * 64 < K) {
+                const int c = lane + 64 * j;
+                w[j] = 0.f;
+                if (c < K) {
+                    const float d = (e[j] + b.q1(c)) - mm;
+                    if (d == 0.f) { n_max += 1.0f; w[j] = 1.0f; }
+                    else { w[j] = exp_nonpos(d); rest += w[j]; }
+                }
+            }
         }
+        n_max = group_sum<64>(n_max); rest = group_sum<64>(rest);
+        lse_m = mm + log_sum_counted(n_max, rest);
+        tot_m = n_max + rest;
     }
-    const float lse_m = mm + sm_m.log_total();
+    const float inv_tot_m = 1.0f / tot_m;
     // loss terms: KL(true || model) (t > 0) or decoder NLL (t == 0) (:555-572), and the prior KL (:544-553)
     float W = 0.f, loss = 0.f, klp = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         if (j == 0 || j * 64 < K) {
             const int c = lane + 64 * j;
-            w[j] = 0.f;
             if (c < K) {
                 const float lm = (e[j] + b.q1(c)) - lse_m;
                 if (b.t == 0) {
-                    w[j] = (c == b.hot0) ? 1.0f : 1e-30f;                        // exp(log_x_start)
-                    loss -= w[j] * lm;
+                    const float wt = (c == b.hot0) ? 1.0f : 1e-30f;              // exp(log_x_start)
+                    loss -= wt * lm;
+                    W += wt;
                 } else {
                     const float2 p = b.posterior(c);
-                    w[j] = p.y;
                     loss += p.y * (p.x - lm);
+                    W += p.y;
                 }
-                W += w[j];
                 klp += (c == b.hot0) ? b.klp_hot : b.klp_cold;
             }
         }
@@ -163,8 +176,8 @@ __device__ __forceinline__ void loss_block_cached(const MLossArgs& a, LBlock& b,
         if (j == 0 || j * 64 < K) {
             const int c = lane + 64 * j;
             if (c < K) {
-                const float lm = (e[j] + b.q1(c)) - lse_m;
-                const float g_un = -w[j] + W * exp_nonpos(lm);
+                const float wt = b.t == 0 ? ((c == b.hot0) ? 1.0f : 1e-30f) : b.posterior(c).y;
+                const float g_un = -wt + W * (w[j] * inv_tot_m);
                 w[j] = g_un * (b.t == 0 ? 1.0f : exp_nonpos((v[j] + b.lca_p) - e[j]));
                 S += w[j];
             }
