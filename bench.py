@@ -167,8 +167,14 @@ def train_bench(device, n_num, T, batch, steps, warmup, barrier):
     barrier()
     dt = time.perf_counter() - t0
     flops = batch * 6.0 * (640 * n_num + 4292608)
+    tf = flops * steps / dt / 1e12
+    # whole-step roofline: algorithmic FLOPs of the step (forward + both backward products of every nn.Linear) per second
+    # against the dense f16 matrix peak; the split products issue three MFMAs per term, hence the /3 ceiling
     return {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3), "batch_per_gpu": batch,
-            "steps_timed": steps, "tflops_per_gpu": round(flops * steps / dt / 1e12, 1)}
+            "steps_timed": steps, "tflops_per_gpu": round(tf, 1),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "frac_of_split_ceiling": round(3.0 * tf / PEAK_F16_MFMA_TFLOPS, 4),
+                         "flops_per_step": flops, "scope": "whole training step (not one kernel): B*6*(640*D_in + 4292608) FLOP"}}
 
 
 def classifier_train_bench(device, n_num, n_clusters, T, batch, steps, warmup, cpu_steps):
@@ -303,6 +309,23 @@ def gmm_bench(device, n_rows, d, k, iters, cpu_rows):
                              "sample": f"{cpu_rows} rows, {dt:.2f} s", "labels_match_gpu": same}}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N rank processes ourselves, as fresh children of a
+    parent that has made no GPU call (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), pass rank 0's JSON
+    line through and return the launcher's exit status (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL needs it)
+    env["CLAVA_BENCH_SPAWNED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
 def trace(msg):
     """Progress markers on stderr (CLAVA_BENCH_TRACE=1): where a multi-rank run stands."""
     if os.environ.get("CLAVA_BENCH_TRACE"):
@@ -328,9 +351,15 @@ def main():
                     help="layer kernels of the sampling loop: split-f16 on the f16 matrix cores (float32-level accuracy) or float32-input MFMA")
     ap.add_argument("--no-scale-sweep", action="store_true", help="skip the step-kernel / scale-sweep (100 num + 50 cat columns) legs")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra chain timed on the float32-input MFMA kernels")
+    ap.add_argument("--no-t2000", action="store_true", help="skip the extra chain at T = 2000 (the configs' num_timesteps)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the launcher (it has not touched the GPU) and exits with the ranks' status
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # CLAVA_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks (ranks share
@@ -341,13 +370,33 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
     else:
         dist = None
+    joined = 1
+    if dist is not None:
+        # ranks that actually joined the group: what `n_gpus` reports
+        one = torch.ones(1, device=f"cuda:{local_rank}") if backend == "nccl" else torch.ones(1)
+        dist.all_reduce(one)
+        joined = int(one.item())
+        if joined != args.gpus:
+            raise SystemExit(f"bench.py: {joined} ranks joined the process group, --gpus {args.gpus} asked for")
+    if os.environ.get("CLAVA_BENCH_SPAWN_CHECK"):
+        # launcher rehearsal (tests/test_host.py, CPU, gloo): the group is up; report it and leave before any GPU work
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": joined, "backend": backend,
+                              "spawned_by_bench": bool(os.environ.get("CLAVA_BENCH_SPAWNED"))}))
+        if os.environ.get("CLAVA_BENCH_SPAWN_CHECK") == "fail":
+            raise SystemExit(3 if rank == world - 1 else 0)    # a failing rank must fail the whole run
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     device = f"cuda:{local_rank}"
@@ -505,6 +554,24 @@ def main():
         api = {"rows_per_s_per_gpu": round(B / dt_api, 1), "ms_per_chain": round(1e3 * dt_api, 1),
                "note": "diffusion.conditional_sample(...) incl. host<->device copies of labels and samples"}
 
+    # the same workload at the configs' own chain length (configs/movie_lens.json:14-45 num_timesteps = 2000):
+    # a second denoiser fitted under the T = 2000 schedule, one warm-up quarter chain, one timed chain
+    t2000 = None
+    if rank == 0 and world == 1 and not args.no_t2000 and T != 2000:
+        diff2, net2, clf2, cond2 = build_workload(device, args.n_num, args.clusters, 2000, args.fit_steps)
+        x2, idx2 = diff2._initial_state(B, None, seed, 0)
+        diff2._run_chain(x2, idx2, cond2, ys, None, seed, 0, n_steps=500)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        x2, keep2 = run_chain(diff2, cond2, ys, seed + 7, 0)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        assert bool(torch.isfinite(x2).all()), "non-finite samples at T = 2000"
+        t2000 = {"timesteps": 2000, "rows_per_s_per_gpu": round(B / dt2, 1), "ms_per_chain": round(1e3 * dt2, 1), "chains_timed": 1,
+                 "sample_absmax": round(float(x2.abs().max()), 3),
+                 "note": "what configs/*.json run (num_timesteps 2000); time is linear in T"}
+        del diff2, net2, clf2, cond2, x2, keep2
+
     gmm = None
     if rank == 0 and world == 1 and not args.no_gmm:              # single-GPU side leg: reported at N = 1 only
         gmm = gmm_bench(device, 1_000_000, 32, 50, 20, 200_000 if not args.no_cpu_baseline else 20_000)
@@ -534,7 +601,7 @@ def main():
     value = rows / elapsed
     out = {
         "metric": f"synth rows/sec ({T}-step reverse diffusion)", "value": round(value, 1), "unit": "rows/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (split-f16x3 MFMA operands, f32 accumulate, 22-bit significand)" if args.gemm == "f16x3" else "f32",
         "data": f"synthetic (N(0,1) table; denoiser fitted {args.fit_steps} Trainer steps to it, classifier random-init)",
@@ -546,6 +613,7 @@ def main():
         "train": train,
         "f32_mfma_path": f32_leg,
         "api_path_incl_pcie": api,
+        "t2000": t2000,
         "gmm_estep": gmm,
         "classifier_train": clf_train,
         "step_kernels": step_kernels,
@@ -565,7 +633,7 @@ def main():
         torch.set_num_threads(threads)
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "rows/s", "cores": threads, "kind": "port",
                                "sample": f"{args.cpu_steps} guided reverse steps (t={T - 1}..{T - args.cpu_steps}) on {cb} rows, "
-                                         f"same networks; {dt:.1f} s of CPU work, extrapolated to {T} steps",
+                                         f"same network shapes (seeded weights); {dt:.1f} s of CPU work, extrapolated to {T} steps",
                                "one_thread": {"value": round(v1, 2), "cores": 1, "sample": f"{n1} steps, {dt1:.1f} s"},
                                "cores_visible": os.cpu_count(),
                                "note": "cores = this process's CPU share (sched affinity, capped by the box's OMP_NUM_THREADS); "

@@ -371,7 +371,14 @@ class ClassifierTrainer:
                 warm.add(key)
                 return None
             if len(graphs) >= 4:
-                graphs.pop(next(iter(graphs)))
+                # least recently used shape out, after its queued replays (their fetch nodes read the pinned buffers from a
+                # kernel, which torch's host allocator does not track)
+                old = graphs.pop(next(iter(graphs)))
+                for ev in old["ev"]:
+                    if ev is not None:
+                        ev.synchronize()
+                if getattr(self, "_graph", None) is old:
+                    self._graph = None
             dev = self.device
             nw = B * n + B + 8
             stage_dev = torch.zeros(nw, device=dev, dtype=torch.float32)
@@ -389,7 +396,10 @@ class ClassifierTrainer:
             gr = graphs[key] = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
                                 "stage": stage_dev, "hyper": self._hyper_dev,
                                 "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * (B * n + B)) for p in pins]}
+        else:
+            graphs[key] = graphs.pop(key)        # most recently used last
         self._graph = gr
+        self._hyper_dev = gr["hyper"]
         par = self._host_step & 1
         if gr["ev"][par] is not None:
             gr["ev"][par].synchronize()          # the replay two steps back, the last reader of this pinned buffer

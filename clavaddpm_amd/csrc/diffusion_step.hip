@@ -98,7 +98,7 @@ __device__ __forceinline__ void multinomial_block(const MultiStepArgs& a, const 
         };
         // Gumbel arg-max (log_sample_categorical, :506-516); ties resolve to the lowest class like torch.argmax
         float best = -INFINITY;
-        int best_c = 0x7fffffff;
+        int best_c = 0;                         // all scores NaN or -inf: class 0, like torch.argmax (and always inside the block)
         auto visit = [&](float v, int c, unsigned word) {
             const float lp = unnormed(v, c) - lse;
             if (a.log_prob) a.log_prob[(size_t)row * a.ld_lp + o + c] = lp;

@@ -43,6 +43,22 @@ __device__ __forceinline__ void glds16(const char* src, char* dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
 }
 
+// 16-byte epilogue store of split planes.  CLAVA_EPI_STORE (experiments): 0 plain, 1 nontemporal, 2 write-through (sc1)
+#ifndef CLAVA_EPI_STORE
+#define CLAVA_EPI_STORE 0
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(char* p, h8 v) {
+#if CLAVA_EPI_STORE == 1
+    __builtin_nontemporal_store(v, reinterpret_cast<h8*>(p));
+#elif CLAVA_EPI_STORE == 2
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(u) : "memory");
+#else
+    *reinterpret_cast<h8*>(p) = v;
+#endif
+}
+
 template <int BN, int BM, int WN, int NS, int NW = 8, int OCC = 1>
 __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs g) {
     constexpr int WM = NW / WN;                               // NW waves: WN along n x WM along m (8 / NW workgroups share a CU)
@@ -290,8 +306,8 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
                     }
                     char* op = g.out_split + (long long)m * g.pitchOut + col_off;
                     if constexpr (EW == 8) {
-                        *reinterpret_cast<h8*>(op) = *reinterpret_cast<const h8*>(hi);
-                        *reinterpret_cast<h8*>(op + 64) = *reinterpret_cast<const h8*>(lo);
+                        store16(op, *reinterpret_cast<const h8*>(hi));
+                        store16(op + 64, *reinterpret_cast<const h8*>(lo));
                     } else {
                         *reinterpret_cast<h4*>(op) = *reinterpret_cast<const h4*>(hi);
                         *reinterpret_cast<h4*>(op + 64) = *reinterpret_cast<const h4*>(lo);
@@ -451,12 +467,30 @@ bool g_attr_set[64][kNumCfgs] = {};   // per device: the LDS limit is a per-devi
 const double kRateTF[] = {384.0, 300.0, 370.0, 270.0, 362.0, 372.0, 285.0, 320.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // 0: never picked by cost
 static_assert(sizeof(kRateTF) / sizeof(kRateTF[0]) == sizeof(kCfgs) / sizeof(kCfgs[0]), "one rate per configuration");
 
+// CLAVA_F16X3_DISABLE="0,8,9": tile configurations the cost model must not pick (experiments)
+unsigned disabled_cfgs() {
+    static const unsigned mask = [] {
+        unsigned m = 0;
+        const char* v = getenv("CLAVA_F16X3_DISABLE");
+        while (v && *v) {
+            char* e = nullptr;
+            const long c = strtol(v, &e, 10);
+            if (e == v) break;
+            if (c >= 0 && c < 32) m |= 1u << c;
+            v = (*e == ',') ? e + 1 : e;
+        }
+        return m;
+    }();
+    return mask;
+}
+
 int pick_cfg(int M, int N, int Kp) {
     int best = kNumCfgs - 1;
     double best_cost = 1e300;
+    const unsigned off = disabled_cfgs();
     for (int c = 0; c < kNumCfgs; ++c) {
         const int bn = kCfgs[c].bn, bm = kCfgs[c].bm;
-        if (kRateTF[c] <= 0.0) continue;
+        if (kRateTF[c] <= 0.0 || (off >> c & 1)) continue;
         if (bn > 64 && N <= bn / 2) continue;
         const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
         const double per_cu = (double)((tiles + 255) / 256);
@@ -471,12 +505,13 @@ int pick_cfg(int M, int N, int Kp) {
     // except the smallest one, which is the fallback of this corner whenever it fits in one round.
     const int one_round[] = {14, 9};
     for (int c : one_round) {
+        if (off >> c & 1) continue;
         const long long tiles = (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((N + kCfgs[c].bn - 1) / kCfgs[c].bn);
         if (tiles <= 256 && (tiles >= 160 || c == 9) && !(kCfgs[c].bn > 64 && N <= kCfgs[c].bn / 2)) return c;
     }
     if (best == 6) {
         const long long tiles = (long long)((M + kCfgs[6].bm - 1) / kCfgs[6].bm) * ((N + kCfgs[6].bn - 1) / kCfgs[6].bn);
-        if (tiles <= 256 && Kp <= 256) best = 8;
+        if (tiles <= 256 && Kp <= 256 && !(off >> 8 & 1)) best = 8;
     }
     return best;
 }

@@ -190,13 +190,18 @@ class PackPlan:
                 dst_t.shift = shift
                 d.dst_t, d.pitch_t = dst_t.buf.data_ptr(), dst_t.pitch
             self.max_tiles = max(self.max_tiles, ((rows + 63) // 64) * ((cols + 63) // 64))
-            self.keep.append((src, dst, dst_t))
+            self.keep.append((src, dst, dst_t, shift))
         self.n = len(items)
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.dev = raw.to(device)
         self.key = tuple((s.data_ptr(), sh) for s, sh, _, _ in items)
 
     def run(self, overflow=None):
+        for _, dst, dst_t, shift in self.keep:       # a cached plan may run again after another plan re-scaled its destinations
+            if dst is not None:
+                dst.shift = shift
+            if dst_t is not None:
+                dst_t.shift = shift
         check(lib().clava_split_pack_multi_f32(ptr(self.dev), c_int(self.n), c_int(self.max_tiles), ptr(overflow), stream_ptr()),
               "clava_split_pack_multi_f32")
 

@@ -221,7 +221,17 @@ class Trainer:
             # one staging buffer and one set of captured graphs PER batch shape (the reference's loader ends every epoch with
             # a short batch: a single slot would re-capture twice per epoch); at most four shapes are kept
             if len(stages) >= 4:
-                stages.pop(next(iter(stages)))
+                # least recently used shape out (`stages` is kept in order of last use).  Its replays may still be queued: the
+                # fetch node reads the pinned buffers from a kernel, which torch's host allocator does not track, so the last
+                # replays are awaited before the buffers and the graphs go.
+                old = stages.pop(next(iter(stages)))
+                for ev in old["ev"]:
+                    if ev is not None:
+                        ev.synchronize()
+                if getattr(self, "_graph", None) is old["graph"]:
+                    self._graph = None
+                if getattr(self, "_cal_graph", None) is old["cal"]:
+                    self._cal_graph = None
             B, Dx = x.shape
             n_x = B * Dx
             stage_dev = torch.zeros(n_x + 8, device=self.flat.device, dtype=torch.float32)
@@ -230,6 +240,8 @@ class Trainer:
                                 "lo": n_x if x.is_cuda else 0, "n": n_x + 8, "hyper": stage_dev[n_x:], "graph": None, "cal": None,
                                 "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * n_x) for p in pins]}
             sg["x"].copy_(x)
+        else:
+            stages[key] = stages.pop(key)                 # most recently used last
         self._hyper_dev = sg["hyper"]                     # what `_adamw_range` bakes into a capture
         return sg
 

@@ -199,18 +199,25 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         ws, bs, acts = fn.stack()
         return [w.detach() for w in ws], [b.detach() for b in bs], acts
 
-    def _run_chain(self, x, idx, guidance, ys, noise, seed, row_offset, n_steps=None):
-        """x float64 [B, n_num] and idx int32 [B, m] are updated in place by clava_sample_chain_f32."""
+    def _run_chain(self, x, idx, guidance, ys, noise, seed, row_offset, n_steps=None, t_start=None):
+        """x float64 [B, n_num] and idx int32 [B, m] are updated in place by clava_sample_chain_f32.
+        `t_start` (default T-1) resumes a chain at a later timestep: x / idx are then the state at t_start, and a float64
+        `noise["z0"]` marks a state that is already past the reference's float32 first step."""
         dev = self._device()
         B = x.shape[0]
         T = self.num_timesteps
-        n_steps = T if n_steps is None else int(n_steps)
+        t_start = T - 1 if t_start is None else int(t_start)
+        if not 0 <= t_start < T:
+            raise ValueError(f"t_start {t_start} outside [0, {T})")
+        n_steps = t_start + 1 if n_steps is None else int(n_steps)
+        if n_steps > t_start + 1:
+            raise ValueError(f"{n_steps} steps from t = {t_start} run past t = 0")
         ws, bs, acts = self._denoiser_stack()
         den, keep_d = _native.make_net(ws, bs, acts)
         den_emb = self._emb_table(self._denoise_fn.time_embed, self._denoise_fn.dim_t)
         c = _native.CChain()
         c.sched = self._c_schedule()
-        c.t_start = T - 1
+        c.t_start = t_start
         c.n_steps = n_steps
         c.n_num, c.m, c.sumK = self.num_numerical_features, self._m, self._sum_k
         c.offsets = self._offsets_i32.data_ptr() if self.has_cat else None
@@ -233,7 +240,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             c.guidance_scale = guidance.classifier_scale
             keep += [keep_c, cls_emb, y32, cnet]
         c.seed, c.row_offset = int(seed), int(row_offset)
-        c.first_step_f32 = 1
+        c.first_step_f32 = 0 if (noise is not None and noise["z0"].dtype == torch.float64) else 1
         if noise is not None:
             nz = noise["noise"][:n_steps].to(dev).double().contiguous()
             c.noise = nz.data_ptr()
@@ -332,7 +339,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return torch.cat(cols, dim=1).cpu()
 
     @torch.no_grad()
-    def conditional_sample(self, ys, model_kwargs=None, cond_fn=None, *, noise=None, seed=None, row_offset=0, n_steps=None):
+    def conditional_sample(self, ys, model_kwargs=None, cond_fn=None, *, noise=None, seed=None, row_offset=0, n_steps=None, t_start=None):
         """Cluster-guided chain for labels `ys` [b, 1] (`:987-1022`); returns (sample float64 CPU [b, n_num], out_dict)."""
         dev = self._device()
         b = len(ys)
@@ -348,20 +355,25 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         from ..pipeline_utils import ClassifierGuidance
         if cond_fn is None or isinstance(cond_fn, ClassifierGuidance):
             labels = self._guidance_labels(model_kwargs, b) if cond_fn is not None else out_dict['y']
-            keep = self._run_chain(x, idx, cond_fn, labels, noise, seed, row_offset, n_steps)
+            keep = self._run_chain(x, idx, cond_fn, labels, noise, seed, row_offset, n_steps, t_start)
         else:
+            if t_start is not None:
+                raise NotImplementedError("t_start with a Python cond_fn")
             keep = self._run_chain_python_guidance(x, cond_fn, model_kwargs or {}, noise, seed, row_offset, n_steps)
         sample = self._finish(x, idx)   # .cpu() synchronises; `keep` may go now
         del keep
         return sample, out_dict
 
     @torch.no_grad()
-    def sample(self, num_samples, y_dist, model_kwargs=None, cond_fn=None, *, noise=None, seed=None, row_offset=0, n_steps=None):
+    def sample(self, num_samples, y_dist, model_kwargs=None, cond_fn=None, *, noise=None, seed=None, row_offset=0, n_steps=None, t_start=None,
+               idx_start=None):
         """Unconditional chain (`:1026-1070`); returns (sample float64 CPU [b, n_num + m], {'y': labels})."""
         dev = self._device()
         b = num_samples
         seed = _fresh_seed() if seed is None else seed
         x, idx = self._initial_state(b, noise, seed, row_offset)
+        if idx_start is not None:                 # resumed chain (tests): the categorical state at t_start
+            idx.copy_(torch.as_tensor(idx_start).to(dev).to(torch.int32))
         if noise is not None and "y" in noise:
             y = noise["y"]
         else:
@@ -375,7 +387,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             # from y_dist above: `conditional_sampling` (pipeline_utils.py:1001-1012) passes its own `classes` there and
             # records them as the rows' clusters
             labels = self._guidance_labels(model_kwargs, b) if cond_fn is not None else out_dict['y']
-            keep = self._run_chain(x, idx, cond_fn, labels, noise, seed, row_offset, n_steps)
+            keep = self._run_chain(x, idx, cond_fn, labels, noise, seed, row_offset, n_steps, t_start)
         else:
             if self.has_cat:
                 raise NotImplementedError("a Python cond_fn with categorical columns is not supported")

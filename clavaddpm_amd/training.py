@@ -226,15 +226,21 @@ class SplitTrainState:
         layers = [(l, True) for l in range(1, n - 1)]
         if wide:
             layers = ([] if gather else [(0, False)]) + layers + [(n - 1, True)]
-        key = tuple((ws[l].data_ptr(), self.shift_w[l]) for l, _ in layers)
-        plan = getattr(self, "_pack_plan", None)
-        if plan is None or plan.key != key:
+        key = tuple((l, ws[l].data_ptr(), self.shift_w[l]) for l, _ in layers)
+        # Plans are kept for the lifetime of this state, one per (layer set, weight storage, scales): a captured step bakes
+        # the address of its plan's device descriptor table into the graph, and the eager steps that run between replays
+        # (the warm-up of a new batch shape takes the dense form of the first layer where the captured step takes the gather
+        # form, i.e. another layer set) must not hand that table back to the allocator under the live graph.  The set of
+        # keys is small: two layer sets x the scale generations of a run (a calibration rarely moves a weight scale).
+        plans = self.__dict__.setdefault("_pack_plans", {})
+        plan = plans.get(key)
+        if plan is None:
             items = []
             for l, both in layers:
                 w = ws[l].detach()
                 items.append((w, self.shift_w[l], self.buf(("w", l), w.shape[0], w.shape[1], device),
                               self.buf(("wt", l), w.shape[1], w.shape[0], device) if both else None))
-            plan = self._pack_plan = ops.PackPlan(items, device)
+            plan = plans[key] = ops.PackPlan(items, device)
         plan.run(self.flag)
 
     def wide(self, d_in):

@@ -374,3 +374,78 @@ def test_fused_narrow_stack_kernels_match_the_per_layer_products(n_num, C, monke
         monkeypatch.setenv("CLAVA_FUSED", fused)
         out[fused], _ = d.sample(b, torch.ones(1), noise=dict(nz, y=torch.zeros(b, dtype=torch.long)), n_steps=steps)
     assert relerr(out["1"], out["0"]) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The END of the chain at config shapes: t = 4 .. 0 covers the `t-1` clamp of the posterior, the
+# no-noise branch at t = 0, `model_variance[0] = posterior_variance[1]` and a float64 state (every step but the first of a
+# full chain); one variant enters with a float32 state, i.e. crosses the float32 -> float64 switch at low t.
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+@pytest.mark.parametrize("n_num,C,z_dtype", [(2, 50, torch.float64), (15, 25, torch.float64), (2, 50, torch.float32)],
+                         ids=["movie_lens_d2", "california_d15", "movie_lens_d2_f32_entry"])
+def test_guided_chain_end_t4_to_t0_vs_oracle(n_num, C, z_dtype, mode):
+    T, b, t_start = 2000, 256, 4
+    ps, cs, d, clf = _guided_setup(n_num, C, T, 151 + n_num, 161 + n_num)
+    g = torch.Generator().manual_seed(300 + n_num)
+    ys = torch.randint(0, C, (b, 1), generator=g)
+    nz = {"z0": torch.randn(b, n_num, generator=g, dtype=z_dtype), "noise": torch.randn(t_start + 1, b, n_num, generator=g).double()}
+    tb = schedule.tables("cosine", T)
+    ref = chain.conditional_sample(tb, T, ps, n_num, lambda x, t: guidance.cond_grad(cs, x, t, ys, 1.0), nz, t_start=t_start)
+    assert ref.dtype == torch.float64
+    split_nets.set_gemm_mode(mode)
+    n0 = split_nets.fallback_count
+    try:
+        x, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1.0), noise=nz, t_start=t_start)
+    finally:
+        split_nets.set_gemm_mode("f16x3")
+    assert split_nets.fallback_count == n0
+    assert relerr(x, ref) < 1e-4
+    assert elem_excess(x, ref) <= 1.0
+    # the last step adds no noise (t = 0): rerunning with another noise[4] must not change the result
+    nz2 = dict(nz, noise=torch.cat([nz["noise"][:t_start], nz["noise"][t_start:] + 1.0]))
+    x2, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1.0), noise=nz2, t_start=t_start)
+    assert torch.equal(x2, d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=make_cond_fn(clf, 1.0), noise=nz, t_start=t_start)[0])
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_scale_sweep_mixed_chain_end_t4_to_t0_vs_oracle(mode):
+    """The scale-sweep table (100 numeric + 50 categorical columns, sum K = 8297) from t = 4 down to t = 0: the categorical
+    posterior's `t == 0` branch (log_EV = log_x0, `:432-441`) and the t-1 clamp; indices exact, numeric columns 1e-4."""
+    K = _scale_sweep_K()
+    n_num, sumK, T, b, t_start = 100, sum(K), 1000, 192, 4
+    state = seeded_state(mlp_shapes(n_num + sumK, DL), 33, scale=0.5)
+    net = MLPDiffusion(n_num + sumK, 0, "none", {"d_layers": list(DL), "dropout": 0.0})
+    net.load_state_dict(state)
+    d = GaussianMultinomialDiffusion(np.array(K), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    nz = _mixed_noise(b, n_num, sumK, t_start + 1, 6)
+    nz["z0"] = nz["z0"].double()
+    g = torch.Generator().manual_seed(17)
+    idx_start = torch.stack([torch.randint(0, k, (b,), generator=g) for k in K], 1)
+    ref = chain.sample(schedule.tables("cosine", T), T, state, n_num, K, nz, t_start=t_start, idx_start=idx_start)
+    split_nets.set_gemm_mode(mode)
+    n0 = split_nets.fallback_count
+    try:
+        x, _ = d.sample(b, torch.ones(1), noise=nz, t_start=t_start, idx_start=idx_start)
+    finally:
+        split_nets.set_gemm_mode("f16x3")
+    assert split_nets.fallback_count == n0
+    assert torch.equal(x[:, n_num:], ref[:, n_num:])              # 192 x 50 x 5 category draws down to t = 0: exact
+    assert relerr(x[:, :n_num], ref[:, :n_num]) < 1e-4
+    assert elem_excess(x[:, :n_num], ref[:, :n_num]) <= 1.0
+
+
+def test_category_flip_rate_at_the_scale_sweep_batch_vs_float64():
+    """the measured rate at which the float32-level pipelines resolve a Gumbel arg-max differently from
+    exact arithmetic, at the FULL scale-sweep batch (4096 rows x 50 features x 4 steps = 819 200 draws), both kernel
+    families, injected uniforms, float64 evaluation of the whole step on the CPU (tools/flip_rate.py; teacher-forced so
+    that a flip does not cascade).  Every flip must be a near-tie (top-2 margin <= 1e-4), and they must be rare."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import flip_rate
+    res = flip_rate.measure(batch=4096, steps=4, f64_device="cpu")
+    print("category flips vs float64:", res)
+    for mode, r in res.items():
+        assert r["draws"] == 4096 * 50 * 4
+        assert r["flips_with_margin_above_1e-4"] == 0, (mode, r)
+        assert r["rate"] < 1e-4, (mode, r)
+        assert r["numeric_max_rel_dev"] < 1e-4, (mode, r)

@@ -149,6 +149,52 @@ def test_cat_input_with_per_row_embedding_matches_the_dense_first_layer(K, n_num
     assert relerr(h32, ref) < 4e-6 and relerr(ops.split_unpack(out), ref) < 4e-6
 
 
+def test_nan_and_inf_logits_give_in_range_indices_through_step_and_gather_layer():
+    """Regression for the round-2 GPU fault: a chain whose activations overflowed hands the categorical step
+    kernel all-NaN / infinite logits.  clava_multinomial_step_f32 must still write an index inside every feature's block
+    (class 0 for an all-NaN block, what torch.argmax of the reference's `:506-516` returns), and clava_cat_input_f32 must
+    accept those indices.  Blocks of every lane-group width (2 .. 300 classes), rows of NaN, +inf, -inf and mixed."""
+    from clavaddpm_amd._lib import c_float, c_int, check, lib, ptr, stream_ptr
+    K, n_num, B = [2, 7, 20, 40, 130, 300], 3, 256
+    d, net, idx, D, g = _cat_table(K, n_num, B, 77)
+    sumK = sum(K)
+    logits = torch.randn(B, sumK, device=DEV, generator=g)
+    logits[0::4] = float("nan")                       # whole rows NaN
+    logits[1::4] = float("inf")
+    logits[2::8] = float("-inf")
+    logits[3::8, ::3] = float("nan")                  # NaN mixed with finite values inside every block
+    t = torch.randint(0, 100, (B,), device=DEV, generator=g)
+    t[:8] = 0
+    offs = d._offsets_i32.long().cpu()
+    for uniforms in (torch.rand(B, sumK, device=DEV, generator=g), None):      # injected and in-kernel draws
+        out, _ = d.p_sample_index(logits, idx, t, uniforms)
+        torch.cuda.synchronize()
+        o = out.cpu().long()
+        for f, k in enumerate(K):
+            assert int(o[:, f].min()) >= 0 and int(o[:, f].max()) < k, (f, k, int(o[:, f].min()), int(o[:, f].max()))
+        assert bool((o[0::4] == 0).all())                      # all-NaN blocks: class 0
+        # the gather layer on those indices (the launch that faulted): finite wherever its own inputs are
+        st = tr.SplitTrainState()
+        gp = st.gather_plan(d, DEV)
+        w = torch.randn(128, D, device=DEV, generator=g) / D ** 0.5
+        b = torch.randn(128, device=DEV, generator=g)
+        emb = torch.randn(B, 128, device=DEV, generator=g)
+        xn = torch.randn(B, n_num, device=DEV, generator=g)
+        st.gather_weights(w, b, n_num)
+        res = ops.split_empty(B, 128, 0, DEV)
+        flag = ops.overflow_flag(DEV)
+        h32 = torch.empty(B, 128, device=DEV)
+        check(lib().clava_cat_input_f32(ptr(xn), c_int(n_num), ptr(out), c_int(B), c_int(n_num), c_int(gp["m"]), c_int(128),
+                                        ptr(d._offsets_i32), ptr(st._wt0), ptr(st._wt0[n_num:]), ptr(st._cat_bias), ptr(emb),
+                                        tr.c_ll(128), c_float(gp["log_tiny"]), c_int(0), ptr(res.buf), tr.c_ll(res.pitch), c_int(3), ptr(h32),
+                                        tr.c_ll(128), ptr(flag), stream_ptr()), "clava_cat_input_f32")
+        torch.cuda.synchronize()
+        x = torch.full((B, sumK), gp["log_tiny"], device=DEV, dtype=torch.float64)
+        x.scatter_(1, out.long() + d._offsets_i32.long()[:-1][None, :], 0.0)
+        ref = torch.cat([xn.double(), x], 1) @ w.double().T + b.double() + emb.double()
+        assert bool(torch.isfinite(h32).all()) and relerr(h32, ref) < 4e-6
+
+
 def test_optimizer_with_device_scalars_is_bit_equal_to_the_argument_form():
     """clava_adamw_hyper_f32 + clava_adamw_ema_hyper_f32 (a captured step's optimizer) against clava_adamw_ema_f32 on the
     same state: identical bits for parameters, moments and EMA."""

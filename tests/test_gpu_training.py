@@ -467,3 +467,56 @@ def test_alternating_batch_shapes_keep_their_captured_graphs():
         assert bool(torch.isfinite(tr.flat).all()) and not torch.equal(tr.flat, w0)
     finally:
         split_nets.set_gemm_mode(prev)
+
+
+def test_alternating_batch_shapes_on_a_wide_table_with_categorical_columns():
+    """on a wide table with categorical columns the captured step packs its weights through a plan
+    WITHOUT layer 0 (gather form of the first layer), while the eager warm-up step of a new batch shape packs layer 0 too.
+    The captured graph holds the address of its plan's device descriptor table, so the eager step must not replace (free)
+    that plan: full, full, full, short, short, short, full - the last replay reads the first plan's table again.  Both
+    shapes keep their graphs, every loss stays finite and the packed operands of the replayed step match a fresh pack."""
+    from clavaddpm_amd import split_nets
+    prev = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode("f16x3")
+    try:
+        torch.manual_seed(0)
+        K, n_num = [100, 80, 60, 30], 40                     # D_in = 310 >= 256: the end layers run on the split kernels
+        net = MLPDiffusion(n_num + sum(K), 0, "none", {"d_layers": [128, 256, 128], "dropout": 0.0}).to(DEV).train()
+        d = GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=100, device=torch.device(DEV)).to(DEV).train()
+        tr = Trainer(d, None, lr=1e-3, weight_decay=0.0, steps=10 ** 6, device=torch.device(DEV))
+        g = torch.Generator().manual_seed(1)
+
+        def batch(B):
+            cats = torch.stack([torch.randint(0, k, (B,), generator=g) for k in K], 1).float()
+            return torch.cat([torch.randn(B, n_num, generator=g), cats], 1)
+
+        y = lambda x: {"y": torch.zeros(len(x), dtype=torch.long)}
+        full, short = batch(512), batch(160)
+        for x in [full] * 4:                                    # calibration, warm-up, capture, replay
+            tr._run_step(x, y(x))
+        st = tr._split_state()
+        assert st.gather_ok(d, net, 512) and st.gather_ok(d, net, 160), "the test must exercise the gather form"
+        plans_full = dict(st._pack_plans)
+        tables = {k: p.dev.data_ptr() for k, p in plans_full.items()}
+        for x in [short] * 3 + [full] * 2 + [short, full, short, short]:
+            lm, lg = tr._run_step(x, y(x))
+            assert bool(torch.isfinite(lg)) and bool(torch.isfinite(lm)), (lm, lg)
+        torch.cuda.synchronize()
+        w_before = [w.detach().clone() for w in net.stack()[0]]     # what the next replay packs (its optimizer runs after the pack)
+        lm, lg = tr._run_step(full, y(full))
+        assert bool(torch.isfinite(lg)) and bool(torch.isfinite(lm)), (lm, lg)
+        graphs = {k: sg["graph"]["graph"] for k, sg in tr._stages.items()}
+        assert len(graphs) == 2 and all(v is not None for v in graphs.values())
+        # every plan a graph may hold is still alive at its address
+        for k, p in plans_full.items():
+            assert st._pack_plans[k] is p and p.dev.data_ptr() == tables[k]
+        assert len(st._pack_plans) >= 2                         # the dense (eager warm-up) and the gather (captured) layer sets
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(tr.flat).all())
+        # the operands the last replay packed are the current weights' planes
+        from clavaddpm_amd import ops
+        for l in range(1, len(w_before) - 1):
+            got = ops.split_unpack(st.bufs[("w", l)])
+            assert torch.allclose(got, w_before[l], rtol=0, atol=2e-6 * float(w_before[l].abs().max())), l
+    finally:
+        split_nets.set_gemm_mode(prev)
