@@ -48,30 +48,47 @@ __global__ void __launch_bounds__(256) nn_partial_kernel(const float* __restrict
     __shared__ float sb[BT][DMAX + 1];
     const int q0 = blockIdx.y * QT, chunk = blockIdx.x, n_lists = gridDim.x * 4;
     const int qi = threadIdx.x & (QT - 1), slice = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < QT * d; e += 256) {
-        const int r = e / d, c = e - r * d;
-        sq[r][c] = (q0 + r < nq) ? A[(long long)(q0 + r) * lda + c] : 0.f;
-    }
+    // tables wider than DMAX columns go through LDS in column chunks; a (query, row) pair's running sum stays in a register
+    // across the chunks, so the float32 accumulation order (column 0, 1, 2, ...) is the same for every width
+    const bool one_chunk = d <= DMAX;
+    auto load_queries = [&](int c0, int dc) {
+        for (int e = threadIdx.x; e < QT * dc; e += 256) {
+            const int r = e / dc, c = e - r * dc;
+            sq[r][c] = (q0 + r < nq) ? A[(long long)(q0 + r) * lda + c0 + c] : 0.f;
+        }
+    };
+    if (one_chunk) load_queries(0, d);
     Top4 top;
     top.init();
     const int b_begin = chunk * rows_per_chunk, b_end = min(nb, b_begin + rows_per_chunk);
     for (int t0 = b_begin; t0 < b_end; t0 += BT) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < BT * d; e += 256) {
-            const int r = e / d, c = e - r * d;
-            sb[r][c] = (t0 + r < b_end) ? B[(long long)(t0 + r) * ldb + c] : 0.f;
-        }
-        __syncthreads();
-        for (int r = slice; r < BT; r += 4) {
-            const int row = t0 + r;
-            if (row >= b_end) break;
-            if (removed && removed[row]) continue;
-            float acc = 0.f;
-            for (int c = 0; c < d; ++c) {
-                const float df = sb[r][c] - sq[qi][c];
-                acc += df * df;
+        float acc[BT / 4];
+#pragma unroll
+        for (int j = 0; j < BT / 4; ++j) acc[j] = 0.f;
+        for (int c0 = 0; c0 < d; c0 += DMAX) {
+            const int dc = min(DMAX, d - c0);
+            __syncthreads();
+            if (!one_chunk) load_queries(c0, dc);
+            for (int e = threadIdx.x; e < BT * dc; e += 256) {
+                const int r = e / dc, c = e - r * dc;
+                sb[r][c] = (t0 + r < b_end) ? B[(long long)(t0 + r) * ldb + c0 + c] : 0.f;
             }
-            top.push(acc, row);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < BT / 4; ++j) {
+                const int r = slice + 4 * j;
+                float a = acc[j];
+                for (int c = 0; c < dc; ++c) {
+                    const float df = sb[r][c] - sq[qi][c];
+                    a += df * df;
+                }
+                acc[j] = a;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BT / 4; ++j) {
+            const int row = t0 + slice + 4 * j;
+            if (row < b_end && !(removed && removed[row])) top.push(acc[j], row);
         }
     }
     if (q0 + qi < nq) {
@@ -120,10 +137,6 @@ int clava_nn_topk_f32(const float* A, long long lda, int nq, const float* B, lon
                       const unsigned char* removed, void* workspace, int* out_idx, float* out_dist, void* stream) {
     CLAVA_CHECK_ARG(A && B && out_idx && out_dist && workspace, "nn_topk: null argument");
     CLAVA_CHECK_ARG(nq > 0 && nb > 0 && d > 0 && lda >= d && ldb >= d, "nn_topk: bad shape nq=%d nb=%d d=%d", nq, nb, d);
-    if (d > DMAX) {
-        clava_set_error("nn_topk: d=%d columns exceeds the supported maximum of %d", d, DMAX);
-        return CLAVA_ERR_LIMIT;
-    }
     hipStream_t st = (hipStream_t)stream;
     const int chunks = chunks_for(nq, nb);
     const int per = ((nb + chunks - 1) / chunks + BT - 1) / BT * BT;

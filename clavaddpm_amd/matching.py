@@ -19,6 +19,7 @@ from ._lib import c_int, check, lib, ptr, stream_ptr
 
 NK = 4                   # candidates per query returned by clava_nn_topk_f32
 QUERY_BATCH = 8192       # queries searched per launch; the greedy pass over a batch runs on the host
+MIN_BATCH = 64           # one query tile of the search kernel: the batch size while a run of duplicate queries lasts
 
 
 def _topk(Ad, Bd, removed):
@@ -77,8 +78,9 @@ def match_tables(A, B, n_clusters=25, unique_matching=True, batch_size=100, devi
     removed = torch.zeros(B.shape[0], device=dev, dtype=torch.uint8)
     taken = np.zeros(B.shape[0], dtype=bool)
     start = 0
+    batch = QUERY_BATCH
     while start < n:
-        stop = min(n, start + QUERY_BATCH)
+        stop = min(n, start + batch)
         idx, dist = _topk(Ad[start:stop], Bd, removed)
         done = 0
         newly = []
@@ -100,6 +102,11 @@ def match_tables(A, B, n_clusters=25, unique_matching=True, batch_size=100, devi
             raise _lib.ClavaHipError("match_tables: no candidate left for a query (fewer free rows in B than queries)")
         removed[torch.as_tensor(newly, device=dev, dtype=torch.long)] = 1
         start += done
+        # A batch that ended early (a query ran out of candidates: near-duplicate queries competing for the same rows) is
+        # searched again from that query.  Only ~NK queries resolve per search while such a run lasts, so the next search
+        # takes few queries instead of QUERY_BATCH it would mostly throw away; the size doubles again after every batch
+        # that completes (the fixed batch made runs of duplicates quadratic).
+        batch = max(MIN_BATCH, min(QUERY_BATCH, 2 * done)) if done < stop - (start - done) else min(QUERY_BATCH, 2 * batch)
     return indices, distances
 
 

@@ -431,8 +431,12 @@ class Trainer:
         self.opt_step, self.lr = snap["opt_step"], snap["lr"]
         sums.copy_(snap["sums"])
         self.loss_history = self.loss_history.iloc[:snap["rows"]].copy()
-        torch.set_rng_state(snap["rng_cpu"])
-        torch.cuda.set_rng_state(snap["rng_dev"], self.flat.device)
+        # Only the torch-generator draw mode (CLAVA_TRAIN_DRAWS=torch) consumes torch's device generator in a step; the default
+        # draws are keyed by the step word restored below.  The CPU generator is never rewound: the data iterator keeps its
+        # position (the window's batches are replayed from the snapshot) and draws its per-epoch shuffle from that generator,
+        # so a rewind would repeat a shuffle already drawn inside the window.
+        if not _tr.DEVICE_DRAWS:
+            torch.cuda.set_rng_state(snap["rng_dev"], self.flat.device)
         self._step_word.copy_(snap["word"])
         self._host_word = snap["host_word"]
         from .. import split_nets

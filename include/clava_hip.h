@@ -595,7 +595,7 @@ int clava_gmm_mstep_finalize_f64(const double* totals, long long N, int d, int k
  * an APPROXIMATE search in a third-party library that is not part of the reference tree): here EXACT.  For every query row
  * A[q, :d] the 4 nearest rows of B[nb, d] whose removed[] byte is 0 (removed may be NULL), by squared L2 distance
  * accumulated column by column in float32, ties to the lower row index: out_idx[q*4 + k] (-1 when fewer than k+1 rows are
- * left), out_dist[q*4 + k], ascending.  d <= 64 (-3 beyond).  workspace: clava_nn_topk_workspace_bytes(nq, nb) bytes. */
+  * left), out_dist[q*4 + k], ascending.  Any d (tables wider than 64 columns are reduced in 64-column chunks).  workspace: clava_nn_topk_workspace_bytes(nq, nb) bytes. */
 long long clava_nn_topk_workspace_bytes(int nq, int nb);
 int clava_nn_topk_f32(const float* A, long long lda, int nq, const float* B, long long ldb, int nb, int d,
                       const unsigned char* removed, void* workspace, int* out_idx, float* out_dist, void* stream);

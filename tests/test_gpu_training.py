@@ -491,11 +491,11 @@ def test_alternating_batch_shapes_on_a_wide_table_with_categorical_columns():
             return torch.cat([torch.randn(B, n_num, generator=g), cats], 1)
 
         y = lambda x: {"y": torch.zeros(len(x), dtype=torch.long)}
-        full, short = batch(512), batch(160)
+        full, short = batch(512), batch(256)
         for x in [full] * 4:                                    # calibration, warm-up, capture, replay
             tr._run_step(x, y(x))
         st = tr._split_state()
-        assert st.gather_ok(d, net, 512) and st.gather_ok(d, net, 160), "the test must exercise the gather form"
+        assert st.gather_ok(d, net, 512) and st.gather_ok(d, net, 256), "the test must exercise the gather form"
         plans_full = dict(st._pack_plans)
         tables = {k: p.dev.data_ptr() for k, p in plans_full.items()}
         for x in [short] * 3 + [full] * 2 + [short, full, short, short]:
