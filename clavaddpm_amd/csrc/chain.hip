@@ -153,8 +153,19 @@ int check_split_net(const clava_split_net* n, bool need_grad, const char* who) {
 }
 
 // forward of a split stack: outs[l] (split rows, shift_out[l]) for l < n-1, last layer to float32 `last` (ld_last)
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+inline long long bits_pitch(int cols) { return ((cols + 31) & ~31) / 8; }
+// layers whose activation derivative travels as bits (split.h): wide enough that its planes would come from memory
+inline bool bits_layer(const clava_split_net* net, int l) {
+    return l + 1 < net->n_layers && net->act[l] != CLAVA_ACT_NONE && net->dims[l + 1] >= 256;
+}
+
 int split_net_forward(const clava_split_net* net, const char* x, int M, const float* rowadd0, char* const* outs, float* last,
-                      int ld_last, int* overflow, hipStream_t st, int l0 = 0) {
+                      int ld_last, int* overflow, hipStream_t st, int l0 = 0, unsigned char* const* bits = nullptr) {
     const char* in = x;                           // l0 > 0: x = activation of layer l0 - 1
     int shift_in = l0 == 0 ? net->shift_in : net->shift_out[l0 - 1];
     for (int l = l0; l < net->n_layers; ++l) {
@@ -171,6 +182,7 @@ int split_net_forward(const clava_split_net* net, const char* x, int M, const fl
         g.out_split = is_last ? nullptr : outs[l]; g.pitchOut = split_pitch(net->dims[l + 1]);
         g.out_f32 = is_last ? last : nullptr; g.ldc = ld_last;
         g.overflow = overflow; g.tiles_m = g.tiles_n = 0;
+        if (bits && bits[l]) { g.bits_out = bits[l]; g.pitchBits = bits_pitch(net->dims[l + 1]); }
         int rc = clava_launch_gemm_f16x3(g, -1, st);
         if (rc) return rc;
         in = outs[l];
@@ -182,7 +194,7 @@ int split_net_forward(const clava_split_net* net, const char* x, int M, const fl
 // input gradient of a split stack: dlast = split rows (shift_dlast) of d/d(last output); grads[l] (split rows,
 // shift_grad[l]) = d/d(pre-activation of layer l-1) for l >= 1; gx = alpha * d/d(input), float32 [M, dims[0]]
 int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, const char* dlast, char* const* grads, float* gx,
-                         int ld_gx, float alpha, int* overflow, hipStream_t st) {
+                         int ld_gx, float alpha, int* overflow, hipStream_t st, unsigned char* const* bits = nullptr) {
     const char* gin = dlast;
     int shift_g = net->shift_dlast;
     for (int l = net->n_layers - 1; l >= 0; --l) {
@@ -193,7 +205,9 @@ int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, c
         g.bias = nullptr; g.bias2 = nullptr; g.act = CLAVA_ACT_NONE;
         g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
         if (l > 0 && net->act[l - 1] != CLAVA_ACT_NONE) {      // derivative of layer l-1's activation, read off its output
-            g.mask = outs[l - 1]; g.pitchMask = split_pitch(net->dims[l]); g.mask_slope = act_slope(net->act[l - 1]);
+            g.mask_slope = act_slope(net->act[l - 1]);
+            if (bits && bits[l - 1]) { g.mask_bits = bits[l - 1]; g.pitchBits = bits_pitch(net->dims[l]); }    // ... or off its bits
+            else { g.mask = outs[l - 1]; g.pitchMask = split_pitch(net->dims[l]); }
         }
         g.scale_acc = ldexpf(1.f, -(shift_g + net->shift_w[l]));
         g.alpha = (l == 0) ? alpha : 1.f;
@@ -299,6 +313,7 @@ struct SplitChainWs {
     char* den[2];       // ping-pong hidden activations
     float* model_out;   // [B, model_out_ld(D)]
     char* cls_out[64];  // classifier activations, kept for the backward pass
+    unsigned char* cls_bits[64];   // their derivative bits (wide layers only, else null)
     float* logits;      // [B, C]
     char* dlogits;      // split rows [B, C]
     char* cls_grad[2];
@@ -319,6 +334,10 @@ void carve_split(const clava_chain* c, const clava_split_net* d, const clava_spl
     w.logits = nullptr; w.dlogits = nullptr; w.gx = nullptr; w.cls_grad[0] = w.cls_grad[1] = nullptr;
     if (k) {
         for (int l = 0; l + 1 < k->n_layers; ++l) w.cls_out[l] = take(B * split_pitch(k->dims[l + 1]));
+        const bool use_bits = env_int("CLAVA_MASK_BITS", 1) != 0;
+        for (int l = 0; l < 64; ++l) w.cls_bits[l] = nullptr;
+        for (int l = 0; l + 1 < k->n_layers; ++l)
+            if (use_bits && bits_layer(k, l)) w.cls_bits[l] = (unsigned char*)take(B * bits_pitch(k->dims[l + 1]));
         const int C = k->dims[k->n_layers];
         w.logits = (float*)take(4LL * B * C);
         w.dlogits = take(B * split_pitch(C));
@@ -383,10 +402,6 @@ StreamPool* stream_pool(int dev, hipStream_t caller) {
     return p->ok ? p : nullptr;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 #define CLAVA_CHECK_HIP(call, what)                                                        \
     do {                                                                                   \
@@ -785,7 +800,11 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     rc = clava_launch_cls_back(ba, st);
                     if (rc) return rc;
                 } else {
-                    rc = split_net_forward(k, x_split, R, c->classifier_emb + (size_t)t * k->dims[1], cls_out, logits, C, overflow, st);
+                    unsigned char* cls_bits[64] = {};
+                    for (int l = 0; l + 1 < nk; ++l)
+                        cls_bits[l] = w.cls_bits[l] ? w.cls_bits[l] + (size_t)r0 * bits_pitch(k->dims[l + 1]) : nullptr;
+                    rc = split_net_forward(k, x_split, R, c->classifier_emb + (size_t)t * k->dims[1], cls_out, logits, C, overflow, st, 0,
+                                           cls_bits);
                     if (rc) return rc;
                     {
                         ProfScope prof(PROF_SELECT_GRAD, 0.0, 8.0 * R * C, st);
@@ -793,7 +812,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                                            dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), R, C);
                         CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
                     }
-                    rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st);
+                    rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st, cls_bits);
                     if (rc) return rc;
                 }
                 grad = gx;

@@ -30,17 +30,17 @@ void clava_set_error(const char* fmt, ...);
 // ---- optional per-launch timing (clava_prof_* in include/clava_hip.h) -----------------------------------------------
 // When enabled, every kernel launch of the library is bracketed by two hipEvents on its own stream and tagged with
 // its kernel family and algorithmic work; bench.py reads the totals for the roofline line.  Disabled: one branch.
+enum { PROF_GEMM_F16X3_CFGS = 15 };
 enum ProfFamily {
     PROF_GEMM_NT_128 = 0, PROF_GEMM_NT_64, PROF_GEMM_NT_128_BN, PROF_GEMM_NT_64_BN, PROF_GEMM_NN_128, PROF_GEMM_NN_64,
     PROF_GEMM_TN_128, PROF_GEMM_TN_64,
     PROF_GAUSS_STEP, PROF_MULTI_STEP, PROF_SELECT_GRAD, PROF_MISC, PROF_LOSS, PROF_ADAMW, PROF_GMM, PROF_BN,
     PROF_GEMM_F16X3,                                   // first of PROF_GEMM_F16X3_CFGS families, one per tile configuration
-    PROF_FUSED_NARROW = PROF_GEMM_F16X3 + 15,          // fused_narrow.hip
+    PROF_FUSED_NARROW = PROF_GEMM_F16X3 + PROF_GEMM_F16X3_CFGS,   // fused_narrow.hip
     PROF_GEMM_F16X3_TN,                                // gemm_f16x3_tn.hip
     PROF_CAT_INPUT,                                    // cat_input.hip
     PROF_N_FAMILIES
 };
-enum { PROF_GEMM_F16X3_CFGS = 15 };
 extern bool g_clava_prof_on;
 void clava_prof_begin_(int family, double flops, double bytes, hipStream_t stream);
 void clava_prof_end_(hipStream_t stream);

@@ -43,22 +43,6 @@ __device__ __forceinline__ void glds16(const char* src, char* dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
 }
 
-// 16-byte epilogue store of split planes.  CLAVA_EPI_STORE (experiments): 0 plain, 1 nontemporal, 2 write-through (sc1)
-#ifndef CLAVA_EPI_STORE
-#define CLAVA_EPI_STORE 0
-#endif
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16(char* p, h8 v) {
-#if CLAVA_EPI_STORE == 1
-    __builtin_nontemporal_store(v, reinterpret_cast<h8*>(p));
-#elif CLAVA_EPI_STORE == 2
-    const u32x4 u = __builtin_bit_cast(u32x4, v);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(u) : "memory");
-#else
-    *reinterpret_cast<h8*>(p) = v;
-#endif
-}
-
 template <int BN, int BM, int WN, int NS, int NW = 8, int OCC = 1>
 __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs g) {
     constexpr int WM = NW / WN;                               // NW waves: WN along n x WM along m (8 / NW workgroups share a CU)
@@ -247,7 +231,8 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
     unsigned amax = 0;                                       // max over stored split values of (bits of |value|): NaN > inf > finite
 
     auto epilogue = [&](auto has_mask, auto out_mode) {
-        constexpr bool MASK = decltype(has_mask)::value;
+        constexpr int MASKM = decltype(has_mask)::value;       // 0: none, 1: the activation's planes, 2: derivative bits
+        constexpr bool MASK = MASKM == 1;
         constexpr bool SPLIT = decltype(out_mode)::value != 1, F32 = decltype(out_mode)::value != 0;
 #pragma unroll
         for (int ip = 0; ip < EP; ++ip) {
@@ -262,6 +247,14 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
             const bool inside = nq + EW <= g.N;
             h8 mh8[TM];
             h4 mh4[TM];
+            unsigned mb[TM];
+            if constexpr (MASKM == 2) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int m = min(m_lane + j * 16, g.M - 1);
+                    mb[j] = g.mask_bits[(long long)m * g.pitchBits + (nq >> 3)];
+                }
+            }
             if constexpr (MASK) {                            // all of this column group's mask loads before the first store
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
@@ -289,6 +282,10 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
                         v[r] *= (mv > 0.f) ? 1.f : g.mask_slope;
                     }
                 }
+                if constexpr (MASKM == 2) {
+#pragma unroll
+                    for (int r = 0; r < EW; ++r) v[r] *= ((mb[j] >> r) & 1u) ? 1.f : g.mask_slope;
+                }
 #pragma unroll
                 for (int r = 0; r < EW; ++r) v[r] *= g.alpha;
                 if (!inside) {
@@ -306,8 +303,14 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
                     }
                     char* op = g.out_split + (long long)m * g.pitchOut + col_off;
                     if constexpr (EW == 8) {
-                        store16(op, *reinterpret_cast<const h8*>(hi));
-                        store16(op + 64, *reinterpret_cast<const h8*>(lo));
+                        *reinterpret_cast<h8*>(op) = *reinterpret_cast<const h8*>(hi);
+                        *reinterpret_cast<h8*>(op + 64) = *reinterpret_cast<const h8*>(lo);
+                        if (g.bits_out) {                // derivative bits of this lane's 8 columns (uniform branch)
+                            unsigned b = 0;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) b |= (hi[r] > (_Float16)0.f ? 1u : 0u) << r;
+                            g.bits_out[(long long)m * g.pitchBits + (nq >> 3)] = (unsigned char)b;
+                        }
                     } else {
                         *reinterpret_cast<h4*>(op) = *reinterpret_cast<const h4*>(hi);
                         *reinterpret_cast<h4*>(op + 64) = *reinterpret_cast<const h4*>(lo);
@@ -329,14 +332,18 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
     };
     using std::integral_constant;
     const int mode = g.out_split ? (g.out_f32 ? 2 : 0) : 1;
-    if (g.mask) {
-        if (mode == 0) epilogue(integral_constant<bool, true>{}, integral_constant<int, 0>{});
-        else if (mode == 1) epilogue(integral_constant<bool, true>{}, integral_constant<int, 1>{});
-        else epilogue(integral_constant<bool, true>{}, integral_constant<int, 2>{});
+    auto run = [&](auto mm) {
+        if (mode == 0) epilogue(mm, integral_constant<int, 0>{});
+        else if (mode == 1) epilogue(mm, integral_constant<int, 1>{});
+        else epilogue(mm, integral_constant<int, 2>{});
+    };
+    if constexpr (EW == 8) {
+        if (g.mask_bits) run(integral_constant<int, 2>{});
+        else if (g.mask) run(integral_constant<int, 1>{});
+        else run(integral_constant<int, 0>{});
     } else {
-        if (mode == 0) epilogue(integral_constant<bool, false>{}, integral_constant<int, 0>{});
-        else if (mode == 1) epilogue(integral_constant<bool, false>{}, integral_constant<int, 1>{});
-        else epilogue(integral_constant<bool, false>{}, integral_constant<int, 2>{});
+        if (g.mask) run(integral_constant<int, 1>{});
+        else run(integral_constant<int, 0>{});
     }
     // |value| <= 65504 <=> bits(|value|) <= 0x477fe000; infinities and NaNs have larger patterns
     if (amax > (0x477fe000u << 1) && g.overflow) *g.overflow = 1;
@@ -484,10 +491,13 @@ unsigned disabled_cfgs() {
     return mask;
 }
 
-int pick_cfg(int M, int N, int Kp) {
+// configurations whose lanes hold 4 (not 8) consecutive output columns: they cannot write / read derivative bits
+constexpr unsigned kOddTnCfgs = (1u << 6) | (1u << 8);
+
+int pick_cfg(int M, int N, int Kp, bool need_bits = false) {
     int best = kNumCfgs - 1;
     double best_cost = 1e300;
-    const unsigned off = disabled_cfgs();
+    const unsigned off = disabled_cfgs() | (need_bits ? kOddTnCfgs : 0u);
     for (int c = 0; c < kNumCfgs; ++c) {
         const int bn = kCfgs[c].bn, bm = kCfgs[c].bm;
         if (kRateTF[c] <= 0.0 || (off >> c & 1)) continue;
@@ -545,7 +555,13 @@ int clava_launch_gemm_f16x3(SplitGemmArgs g, int cfg, hipStream_t stream) {
     // at most 16 outputs, float32 result (a head, the last input-gradient product): memory bound, no tile to fill
     static const bool narrow_on = !(getenv("CLAVA_NARROW_SPLIT") && getenv("CLAVA_NARROW_SPLIT")[0] == '0');
     if (cfg < 0 && narrow_on && clava_narrow_split_ok(g)) return clava_launch_narrow_split(g, stream);
-    if (cfg < 0) cfg = pick_cfg(g.M * slabs, g.N, slabs > 1 ? g.kb_per_slab * 32 : g.Kp);
+    const bool bits = g.bits_out || g.mask_bits;
+    if (bits) {
+        CLAVA_CHECK_ARG(g.pitchBits >= Np / 8 && !(g.mask_bits && g.mask) && (!g.bits_out || g.out_split),
+                        "gemm_f16x3: derivative bits need rows of >= round_up(N,32)/8 bytes, a split output, and replace the plane mask");
+        CLAVA_CHECK_ARG(cfg < 0 || !((kOddTnCfgs >> cfg) & 1), "gemm_f16x3: tile configuration %d cannot handle derivative bits", cfg);
+    }
+    if (cfg < 0) cfg = pick_cfg(g.M * slabs, g.N, slabs > 1 ? g.kb_per_slab * 32 : g.Kp, bits);
     const TileCfg& tc = kCfgs[cfg];
     const int lds = tc.ns * (tc.bn + tc.bm) * 128;
     int dev = 0;

@@ -45,6 +45,14 @@ struct SplitGemmArgs {
     // out_colsum[slab * slab_stride + n], scaled by scale_colsum (2^-shift of dy); or null
     float* out_colsum = nullptr;
     float scale_colsum = 0.f;
+    // Activation-derivative masks as BITS (the guidance chain): a forward product with `bits_out` also writes, per row, one
+    // byte per 8 output columns whose bit r says "stored hi-plane value of column 8*g + r is > 0"; the input-gradient
+    // product reads `mask_bits` instead of the activation's planes (`mask`): 1/32 of the bytes (reading the hi plane alone
+    // still pulls whole 128-byte lines, hi | lo, from memory).  Rows pitchBits bytes apart, >= round_up(N, 32) / 8.
+    // Only tile configurations whose lanes hold 8 consecutive columns take these (the launcher picks among those).
+    unsigned char* bits_out = nullptr;
+    const unsigned char* mask_bits = nullptr;
+    long long pitchBits = 0;
 };
 
 // cfg < 0: pick the tile configuration for the shape; otherwise force configuration `cfg` (tools/bench_f16x3.py)
