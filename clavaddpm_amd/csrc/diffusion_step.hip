@@ -15,6 +15,7 @@
 // including its dtype promotions (float64 chain state); the file is compiled with
 // -ffp-contract=off so that a*b + c*d rounds like the separate ATen ops do.
 #include <cstdlib>
+#include <cstring>
 #include "rng.h"
 #include "step.h"
 #include "wave.h"
@@ -203,8 +204,177 @@ __device__ __forceinline__ void multinomial_block(const MultiStepArgs& a, const 
     }
 }
 
+// ---- inverse-CDF form of the reverse step's categorical draw (production path: in-kernel draws only) -------------------
+// The Gumbel arg-max above spends 2 exp + 3 log and a quarter of a Philox call PER CLASS.  The distribution it samples,
+// p(x_{t-1} = c | x_t, x0_hat) (q_posterior of the predicted x_0, `:426-455`), is known in probability space:
+//     w_c = (abar_{t-1} * softmax(logits)_c + (1 - abar_{t-1}) / K) * s_c,      s_c = s_hot if c == x_t else s_cold,
+// (s = exp of the two-valued q_pred_one_timestep factor; at t = 0 the mixing is skipped: w_c = softmax_c * s_c, `:437-441`),
+// so one uniform u per (row, feature) block and the first class whose running sum reaches u * sum(w) draw from the SAME
+// distribution with one exp per class, a DPP prefix sum per 64 classes and one Philox call per block.  The draws differ
+// from the Gumbel path's (another use of the random words), like the closed-form q-sample of the training draws; parity
+// tests with injected uniforms always take the Gumbel path, and tests/test_gpu_icdf.py holds this path to the exact
+// posterior probabilities.
+template <int CTRL> __device__ __forceinline__ float dpp_shr_f(float v) {       // row_shr:N, zero fill at the row start
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// inclusive prefix sum over each group of G lanes (lane order)
+template <int G> __device__ __forceinline__ float group_scan(float v) {
+    constexpr int R = G < 16 ? G : 16;
+    const int l = threadIdx.x & (R - 1);
+    float t;
+    t = dpp_shr_f<0x111>(v); if (l >= 1) v += t;
+    t = dpp_shr_f<0x112>(v); if (l >= 2) v += t;
+    t = dpp_shr_f<0x114>(v); if (l >= 4) v += t;
+    if (R == 16) { t = dpp_shr_f<0x118>(v); if (l >= 8) v += t; }
+    if (G == 32) {                      // rows 0,1 / 2,3 of the wavefront form a group: the odd row adds the even row's total
+        const float lo = __shfl(v, (threadIdx.x & 32) | 15, 64);
+        if (threadIdx.x & 16) v += lo;
+    }
+    if (G == 64) {
+        const int i = __float_as_int(v);
+        const float t0 = __int_as_float(__builtin_amdgcn_readlane(i, 15)), t1 = __int_as_float(__builtin_amdgcn_readlane(i, 31)),
+                    t2 = __int_as_float(__builtin_amdgcn_readlane(i, 47));
+        const int row = (threadIdx.x >> 4) & 3;
+        v += (row == 0) ? 0.f : (row == 1) ? t0 : (row == 2) ? (t0 + t1) : ((t0 + t1) + t2);
+    }
+    return v;
+}
+
+// The CDF runs over the classes in LANE-MAJOR order: lane l owns classes l, l + G, l + 2G, ... (Q of them: 1 for the narrow
+// lane groups, 2 .. 16 for a 64-lane block of up to 1024 classes; wider blocks go through in 1024-class chunks), i.e. the
+// loads stay lane-strided and coalesced, the running sum inside a lane's run needs no cross-lane work, and ONE prefix sum
+// over the lane totals orders the runs.  Any fixed class order is a valid inverse CDF; this one costs a scan and three
+// reductions per block instead of per 64 classes.
+struct IcdfBlock {
+    float A, U, s_hot, s_cold;
+    int K, hot;
+    const float* lg;
+};
+
+template <int G, int Q>
+__device__ __forceinline__ int icdf_resident(const IcdfBlock& b, float u, int lane) {
+    float v[Q];
+    float m1 = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int c = lane + j * G;
+        v[j] = (c < b.K) ? b.lg[c] : -INFINITY;
+        m1 = fmaxf(m1, v[j]);
+    }
+    const float mx = group_max<G>(m1);
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) { v[j] = exp_nonpos(v[j] - mx); sm += v[j]; }       // exp(-inf) = 0 beyond K
+    const float rS = b.A * __builtin_amdgcn_rcpf(group_sum<G>(sm));
+    float run = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {                                                    // v[j] <- running sum of the lane's weights
+        const int c = lane + j * G;
+        const float w = (c < b.K) ? (v[j] * rS + b.U) * (c == b.hot ? b.s_hot : b.s_cold) : 0.f;
+        run += w;
+        v[j] = run;
+    }
+    const float incl = group_scan<G>(run);
+    const float before = incl - run;
+    // total from the scan itself (last lane's inclusive sum), so that target <= the largest running sum up to rounding
+    const float total = (G == 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63))
+                                  : __shfl(incl, (threadIdx.x & 63 & ~(G - 1)) | (G - 1), 64);
+    const float target = u * total;
+    int key = 0x7fffffff;                                                            // position in CDF order: lane * Q + j
+#pragma unroll
+    for (int j = Q - 1; j >= 0; --j)
+        if (lane + j * G < b.K && before + v[j] >= target) key = lane * Q + j;
+    key = group_min<G>(key);
+    // no running sum reached the target: u * total beyond the last sum by rounding -> the last class; NaN weights -> class 0
+    return key == 0x7fffffff ? (total == total ? b.K - 1 : 0) : (key / Q) + (key % Q) * G;
+}
+
+template <int G>
+__device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, const int* s_off, const float* s_logk, bool staged,
+                                                       int row, int f, bool active) {
+    const int lane = threadIdx.x & (G - 1);
+    if (!active) return;
+    int o = staged ? s_off[f] : a.offsets[f];
+    int K = (staged ? s_off[f + 1] : a.offsets[f + 1]) - o;
+    int hot = a.idx_in[(size_t)row * a.m + f];
+    if (G == 64) {
+        o = __builtin_amdgcn_readfirstlane(o);
+        K = __builtin_amdgcn_readfirstlane(K);
+        hot = __builtin_amdgcn_readfirstlane(hot);
+    }
+    const int t = a.t_rows ? (int)a.t_rows[row] : a.t;
+    const float logk = staged ? s_logk[f] : a.log_k[f];
+    const int tp = max(t - 1, 0);
+    IcdfBlock b;
+    // probability-space constants of the block (float32 exp of the reference's float32 log tables)
+    b.A = (t != 0) ? expf(a.s.log_cumprod_alpha[tp]) : 1.f;
+    b.U = (t != 0) ? expf(a.s.log_1_min_cumprod_alpha[tp] - logk) : 0.f;
+    const float la = a.s.log_alpha[t], un = a.s.log_1_min_alpha[t] - logk;
+    b.s_hot = expf(log_add_exp(0.f + la, un));
+    b.s_cold = expf(log_add_exp(LOG_TINY + la, un));
+    b.K = K; b.hot = hot;
+    b.lg = a.logits + (size_t)row * a.ld_logits + o;
+    const unsigned long long pair_id = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.m + f;
+    const unsigned step_key = a.step_index + (a.step_counter ? *a.step_counter : 0u);
+    const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, pair_id, step_key, clava_rng::STREAM_CAT | (0x1fffffu << 3));
+    // 24 random bits -> (0, 1]: the search looks for the first running sum >= u * total
+    const float u = ((float)(r.x >> 8) + 1.0f) * 5.9604644775390625e-8f;
+    int best_c;
+    if (G < 64 || K <= 64) best_c = icdf_resident<G, 1>(b, u, lane);
+    else if (K <= 128) best_c = icdf_resident<G, 2>(b, u, lane);
+    else if (K <= 256) best_c = icdf_resident<G, 4>(b, u, lane);
+    else if (K <= 512) best_c = icdf_resident<G, 8>(b, u, lane);
+    else if (K <= 1024) best_c = icdf_resident<G, 16>(b, u, lane);
+    else {
+        // beyond 1024 classes: 1024-class chunks (16 per lane, lane-strided) streamed three times (maximum, softmax sum, search)
+        constexpr int Q = 16, CH = G * Q;
+        float m1 = -INFINITY;
+        for (int cb = 0; cb < K; cb += CH)
+#pragma unroll
+            for (int j = 0; j < Q; ++j) { const int c = cb + lane + j * G; if (c < K) m1 = fmaxf(m1, b.lg[c]); }
+        const float mx = group_max<G>(m1);
+        float sm = 0.f;
+        for (int cb = 0; cb < K; cb += CH)
+#pragma unroll
+            for (int j = 0; j < Q; ++j) { const int c = cb + lane + j * G; if (c < K) sm += exp_nonpos(b.lg[c] - mx); }
+        const float rS = b.A * __builtin_amdgcn_rcpf(group_sum<G>(sm));
+        const bool hot_ok = hot >= 0 && hot < K;
+        const float e_hot = hot_ok ? exp_nonpos(b.lg[hot] - mx) : 0.f;
+        const float total = b.s_cold * (b.A + (float)K * b.U) + (hot_ok ? (b.s_hot - b.s_cold) * (e_hot * rS + b.U) : 0.f);
+        const float target = u * total;
+        float base = 0.f;
+        best_c = -1;
+        for (int cb = 0; cb < K && best_c < 0; cb += CH) {       // (best_c is wave-uniform: the loop ends at the chunk that holds the draw)
+            float run = 0.f, cs[Q];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const int c = cb + lane + j * G;
+                run += (c < K) ? (exp_nonpos(b.lg[c] - mx) * rS + b.U) * (c == hot ? b.s_hot : b.s_cold) : 0.f;
+                cs[j] = run;
+            }
+            const float incl = group_scan<G>(run);
+            const float before = base + (incl - run);
+            int key = 0x7fffffff;
+#pragma unroll
+            for (int j = Q - 1; j >= 0; --j)
+                if (cb + lane + j * G < K && before + cs[j] >= target) key = lane * Q + j;
+            key = group_min<G>(key);
+            if (key != 0x7fffffff) best_c = cb + (key / Q) + (key % Q) * G;
+            base += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+        }
+        if (best_c < 0) best_c = (total == total) ? K - 1 : 0;
+    }
+    if (lane == 0) a.idx_out[(size_t)row * a.m + f] = best_c;
+    if (a.x_in) {
+        float* xo = a.x_in + (size_t)row * a.ld_xin + o;
+        for (int c = lane; c < K; c += G) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
+    }
+    if (a.xs.base)
+        for (int c = lane; c < K; c += G) store_split(a.xs, row, a.xs.col0 + o + c, (c == best_c) ? 0.f : LOG_TINY);
+}
+
 // All (row, feature) blocks of the `n_feat` features listed in `perm`, 64 / G blocks of one row per wavefront work item.
-template <int G, int MODE>
+template <int G, int MODE, bool ICDF>
 __device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const int* s_off, const float* s_logk, const float* s_side,
                                                    const int* perm, int n_feat, long long wave0, long long n_waves) {
     constexpr int PER = 64 / G;
@@ -221,12 +391,14 @@ __device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const
     for (; row < a.B; row += d_row, w += d_w) {
         if (w >= W) { w -= W; ++row; if (row >= a.B) break; }
         const int fi = w * PER + sub;
-        multinomial_block<G, MODE>(a, s_off, s_logk, s_side, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
+        if constexpr (ICDF) multinomial_block_icdf<G>(a, s_off, s_logk, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
+        else multinomial_block<G, MODE>(a, s_off, s_logk, s_side, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
     }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) {
+// ICDF: the inverse-CDF sampler (REVERSE only) as a kernel of its own - its register budget differs from the Gumbel form's
+template <int MODE, bool ICDF = false>
+__global__ void __launch_bounds__(256, ICDF ? 5 : 1) multinomial_step_kernel(MultiStepArgs a) {
     __shared__ int s_off[MAX_LDS_FEATURES + 1];
     __shared__ float s_logk[MAX_LDS_FEATURES];
     __shared__ float s_side[2 * MAX_LDS_FEATURES];
@@ -244,7 +416,8 @@ __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) 
         const int d_row = (int)(n_waves / a.m), d_f = (int)(n_waves - (long long)d_row * a.m);
         for (; row < a.B; row += d_row, f += d_f) {
             if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
-            multinomial_block<64, MODE>(a, s_off, s_logk, s_side, false, row, f, true);
+            if constexpr (ICDF) multinomial_block_icdf<64>(a, s_off, s_logk, false, row, f, true);
+            else multinomial_block<64, MODE>(a, s_off, s_logk, s_side, false, row, f, true);
         }
         return;
     }
@@ -267,10 +440,10 @@ __global__ void __launch_bounds__(256) multinomial_step_kernel(MultiStepArgs a) 
     const int st1 = s_start[1], st2 = s_start[2], st3 = s_start[3];
     const int n0 = st1, n1 = st2 - st1, n2 = st3 - st2, n3 = a.m - st3;
     // one loop per width (a single loop over mixed items would keep all four variants' registers live at once)
-    multinomial_bucket<8, MODE>(a, s_off, s_logk, s_side, s_perm, n0, wave0, n_waves);
-    multinomial_bucket<16, MODE>(a, s_off, s_logk, s_side, s_perm + st1, n1, wave0, n_waves);
-    multinomial_bucket<32, MODE>(a, s_off, s_logk, s_side, s_perm + st2, n2, wave0, n_waves);
-    multinomial_bucket<64, MODE>(a, s_off, s_logk, s_side, s_perm + st3, n3, wave0, n_waves);
+    multinomial_bucket<8, MODE, ICDF>(a, s_off, s_logk, s_side, s_perm, n0, wave0, n_waves);
+    multinomial_bucket<16, MODE, ICDF>(a, s_off, s_logk, s_side, s_perm + st1, n1, wave0, n_waves);
+    multinomial_bucket<32, MODE, ICDF>(a, s_off, s_logk, s_side, s_perm + st2, n2, wave0, n_waves);
+    multinomial_bucket<64, MODE, ICDF>(a, s_off, s_logk, s_side, s_perm + st3, n3, wave0, n_waves);
 }
 
 // forward noising of the numeric columns, per-row t (gaussian_q_sample, :172-180)
@@ -422,7 +595,29 @@ int clava_launch_gauss_step(const GaussStepArgs& a, hipStream_t stream) {
     return CLAVA_OK;
 }
 
-int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
+// Sampler of the reverse step's in-kernel categorical draws: 0 = Gumbel arg-max (the reference's construction, `:506-516`),
+// 1 = inverse CDF (same distribution, ~3x fewer instructions).  Injected uniforms and log-probability requests always take
+// the Gumbel path.  Default from CLAVA_CAT_SAMPLER (gumbel / icdf); clava_categorical_sampler_set() overrides it.
+static int g_cat_sampler = -1;
+static int cat_sampler() {
+    if (g_cat_sampler < 0) {
+        const char* v = getenv("CLAVA_CAT_SAMPLER");
+        g_cat_sampler = (v && (v[0] == 'g' || v[0] == '0')) ? 0 : (v && strstr(v, "always")) ? 2 : 1;
+    }
+    return g_cat_sampler;
+}
+extern "C" int clava_categorical_sampler_set(int mode) {
+    const int prev = cat_sampler();
+    if (mode >= 0 && mode <= 2) g_cat_sampler = mode;
+    return prev;
+}
+
+int clava_launch_multinomial_step(const MultiStepArgs& a_in, hipStream_t stream) {
+    MultiStepArgs a = a_in;
+    // (measured: 590 vs 678 us at 20000 rows x 50 features of ~165 classes, but 25 vs 22 us on 8 features of ~5 classes: the
+    // inverse CDF only pays on wide blocks; CLAVA_CAT_SAMPLER=icdf_always forces it)
+    a.icdf = (a.mode == MULTI_MODE_REVERSE && !a.uniforms && !a.log_prob && cat_sampler() >= 1 &&
+              (cat_sampler() == 2 || a.sumK >= 32LL * a.m)) ? 1 : 0;
     CLAVA_CHECK_ARG(a.B > 0 && a.m > 0 && a.sumK > 0, "multinomial_step: empty shape");
     CLAVA_CHECK_ARG(a.idx_out && a.offsets && a.log_k, "multinomial_step: null idx_out/offsets/log_k");
     CLAVA_CHECK_ARG(a.mode == MULTI_MODE_INIT || a.idx_in, "multinomial_step: idx_in required");
@@ -431,23 +626,26 @@ int clava_launch_multinomial_step(const MultiStepArgs& a, hipStream_t stream) {
     const long long pairs = (long long)a.B * a.m;
     const long long blocks = (pairs + 3) / 4;
     // persistent grid: as many workgroups as the chip holds at once, so that every wavefront averages over many blocks
-    static int resident[64][3] = {};
+    static int resident[64][4] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!resident[dev][a.mode]) {
-        const void* fn = a.mode == MULTI_MODE_REVERSE ? (const void*)multinomial_step_kernel<MULTI_MODE_REVERSE>
+    const int slot = a.icdf ? 3 : a.mode;
+    if (!resident[dev][slot]) {
+        const void* fn = a.icdf ? (const void*)multinomial_step_kernel<MULTI_MODE_REVERSE, true>
+                         : a.mode == MULTI_MODE_REVERSE ? (const void*)multinomial_step_kernel<MULTI_MODE_REVERSE>
                          : a.mode == MULTI_MODE_INIT  ? (const void*)multinomial_step_kernel<MULTI_MODE_INIT>
                                                       : (const void*)multinomial_step_kernel<MULTI_MODE_QSAMPLE>;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         const char* mult = getenv("CLAVA_STEP_GRID_MULT");
-        resident[dev][a.mode] = per_cu * cus * (mult ? atoi(mult) : 1);
+        resident[dev][slot] = per_cu * cus * (mult ? atoi(mult) : 1);
     }
-    const int grid = (int)(blocks < resident[dev][a.mode] ? blocks : resident[dev][a.mode]);
+    const int grid = (int)(blocks < resident[dev][slot] ? blocks : resident[dev][slot]);
     // algorithmic bytes: logits 4/class in, log-one-hot 4/class out (+ injected uniforms 4/class), indices 4+4 per feature
     ProfScope prof(PROF_MULTI_STEP, 0.0, (double)a.B * ((double)a.sumK * ((a.logits ? 4 : 0) + (a.x_in ? 4 : 0) + (a.xs.base ? 4 : 0) + (a.uniforms ? 4 : 0)) + 8.0 * a.m), stream);
-    if (a.mode == MULTI_MODE_REVERSE) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_REVERSE>, dim3(grid), dim3(256), 0, stream, a);
+    if (a.icdf) hipLaunchKernelGGL((multinomial_step_kernel<MULTI_MODE_REVERSE, true>), dim3(grid), dim3(256), 0, stream, a);
+    else if (a.mode == MULTI_MODE_REVERSE) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_REVERSE>, dim3(grid), dim3(256), 0, stream, a);
     else if (a.mode == MULTI_MODE_INIT) hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_INIT>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(multinomial_step_kernel<MULTI_MODE_QSAMPLE>, dim3(grid), dim3(256), 0, stream, a);
     CLAVA_CHECK_LAUNCH("clava_multinomial_step");

@@ -49,6 +49,7 @@ struct MultiStepArgs {
     unsigned long long seed, row_offset;
     unsigned step_index;
     const unsigned* step_counter = nullptr;   // optional device word added to step_index (a graph replay draws afresh)
+    int icdf = 0;                             // REVERSE with in-kernel draws: sample by inverse CDF (one uniform per block)
 };
 
 // first denoiser layer from (numeric columns, category indices): cat_input.hip

@@ -198,6 +198,14 @@ int clava_multinomial_step_counter_f32(const clava_schedule* sched, int mode, in
                                        unsigned long long row_offset, unsigned step_index, const unsigned* step_counter,
                                        void* stream);
 
+/* Sampler of the reverse step's categorical draws when the kernel draws its own noise (uniforms == NULL, log_prob == NULL):
+ * 0 = Gumbel arg-max over the K posterior log-probabilities, the reference's construction (log_sample_categorical,
+ * tab_ddpm/gaussian_multinomial_diffsuion.py:506-516, called from p_sample :468-472); 1 = inverse CDF of the same posterior
+ * p(x_{t-1} | x_t, x0_hat) (:426-455) evaluated in probability space, one uniform per (row, feature) block (default, taken
+ * for tables that average >= 32 classes per feature; 2 = for every table; same distribution, other draws).  Injected uniforms always take the Gumbel form.  Returns the previous setting; any other
+ * `mode` only queries.  Process-wide; CLAVA_CAT_SAMPLER=gumbel|icdf sets the initial value. */
+int clava_categorical_sampler_set(int mode);
+
 /* x_t[B,n_num] = sqrt_alphas_cumprod[t] * x0 + sqrt_one_minus_alphas_cumprod[t] * noise, per-row t (int64):
  * gaussian_q_sample (:172-180), float32. */
 int clava_gauss_qsample_f32(const clava_schedule* sched, int B, int n_num, const float* x0, const float* noise,

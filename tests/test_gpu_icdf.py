@@ -1,0 +1,96 @@
+"""The inverse-CDF sampler of the reverse step's categorical draws (production path, in-kernel noise) against the EXACT
+posterior p(x_{t-1} | x_t, x0_hat) of the reference (`q_posterior(predict_start(model_out), log_x_t, t)`,
+tab_ddpm/gaussian_multinomial_diffsuion.py:414-455), evaluated in float64 by the oracle.  The Gumbel arg-max path (the
+reference's own construction, `:506-516`) is held to the same bars in the same test: both must draw from that distribution.
+Bit parity on injected uniforms stays with the Gumbel path (tests/test_gpu_parity.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clavaddpm_amd._lib import lib
+from clavaddpm_amd.tab_ddpm import GaussianMultinomialDiffusion, MLPDiffusion
+from oracle import multinomial as omn, schedule
+
+DEV = "cuda"
+
+
+@pytest.fixture(params=["icdf", "gumbel"])
+def sampler(request):
+    prev = lib().clava_categorical_sampler_set(ctypes.c_int(2 if request.param == "icdf" else 0))
+    yield request.param
+    lib().clava_categorical_sampler_set(ctypes.c_int(prev))
+
+
+def _exact_posterior(tb, logits_row, idx_t, t, K):
+    """float64 probabilities per feature from the oracle's exact-normaliser p_pred on one row."""
+    lo = torch.from_numpy(logits_row[None, :]).float()
+    log_xt = omn.index_to_log_onehot(torch.tensor(idx_t)[None, :], K)
+    lp = omn.p_pred_exact_norm(tb, lo, log_xt, torch.tensor([t]), K)[0].double().exp().numpy()
+    off = omn.offsets(K)
+    return [lp[off[f]:off[f + 1]] / lp[off[f]:off[f + 1]].sum() for f in range(len(K))]
+
+
+@pytest.mark.parametrize("t", [0, 1, 25, 49])
+def test_reverse_step_draws_follow_the_exact_posterior(sampler, t):
+    """2^18 rows with the same logits / x_t per (t, feature): class frequencies within 5 sigma of the exact posterior for
+    every class, chi-square over the classes with at least 8 expected draws; features of every lane-group width, a
+    1000-class feature (16 classes per lane), a 1500-class one (streamed in 1024-class chunks) and peaked as well as flat logits."""
+    K, T, B = [2, 5, 13, 40, 300, 1000, 1500], 50, 1 << 18
+    rng = np.random.RandomState(11 + t)
+    sumK = sum(K)
+    logits_row = (rng.standard_normal(sumK) * np.repeat([0.5, 2.0, 1.0, 3.0, 1.5, 2.5, 2.0], K)).astype(np.float32)
+    idx_t = [1, 3, 12, 0, 150, 999, 1100]
+    net = MLPDiffusion(sumK, 0, "none", {"d_layers": [32, 32], "dropout": 0.0}).to(DEV)
+    d = GaussianMultinomialDiffusion(np.array(K), 0, net, num_timesteps=T, device=torch.device(DEV)).to(DEV)
+    tb = schedule.tables("cosine", T)
+    want = _exact_posterior(tb, logits_row, idx_t, t, K)
+    logits = torch.from_numpy(logits_row).to(DEV)[None, :].expand(B, sumK).contiguous()
+    idx = torch.tensor(idx_t, dtype=torch.int32, device=DEV)[None, :].expand(B, len(K)).contiguous()
+    tt = torch.full((B,), t, dtype=torch.long, device=DEV)
+    out, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=3)
+    out = out.cpu().numpy()
+    for f, k in enumerate(K):
+        assert out[:, f].min() >= 0 and out[:, f].max() < k
+        freq = np.bincount(out[:, f], minlength=k) / B
+        p = want[f]
+        sigma = np.sqrt(p * (1 - p) / B)
+        worst = np.max(np.abs(freq - p) - 5.0 * sigma)      # ~23 000 class frequencies are compared: 5 sigma each
+        assert worst < 2e-6, (sampler, t, k, worst)
+        big = p * B >= 8
+        chi = float((((freq[big] - p[big]) * B) ** 2 / (p[big] * B)).sum())
+        dof = int(big.sum()) - 1
+        if dof >= 2:
+            assert chi < dof + 4.5 * (2 * dof) ** 0.5, (sampler, t, k, chi, dof)
+    # a pure function of (seed, step, global row, feature): the same call repeats, another step index draws afresh
+    again, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=3)
+    other, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=4)
+    assert np.array_equal(again.cpu().numpy(), out)
+    assert float((other.cpu().numpy() != out)[:, 4:].mean()) > 0.002       # (a peaked posterior repeats most draws)
+
+
+def test_icdf_draws_do_not_depend_on_how_rows_are_cut(sampler):
+    """Row-offset keyed draws: rows [a, b) of one launch equal a launch of those rows alone with row_offset = a."""
+    from clavaddpm_amd._lib import c_int, check, ptr, stream_ptr
+    K, T, B = [3, 17, 70, 400], 20, 3000
+    g = torch.Generator(device=DEV).manual_seed(3)
+    net = MLPDiffusion(sum(K), 0, "none", {"d_layers": [32, 32], "dropout": 0.0}).to(DEV)
+    d = GaussianMultinomialDiffusion(np.array(K), 0, net, num_timesteps=T, device=torch.device(DEV)).to(DEV)
+    logits = torch.randn(B, sum(K), device=DEV, generator=g) * 2
+    idx = torch.stack([torch.randint(0, k, (B,), device=DEV, generator=g) for k in K], 1).to(torch.int32).contiguous()
+    sched = d._c_schedule()
+
+    def run(a, b, row_offset):
+        out = torch.empty((b - a, len(K)), device=DEV, dtype=torch.int32)
+        lg = logits[a:b].contiguous()
+        check(lib().clava_multinomial_step_f32(ctypes.byref(sched), c_int(0), c_int(b - a), c_int(len(K)), c_int(sum(K)), ptr(d._offsets_i32),
+                                               ptr(d._log_k), ptr(lg), c_int(sum(K)), ptr(idx[a:b].contiguous()), ptr(out), None, c_int(sum(K)),
+                                               None, c_int(0), None, c_int(0), None, c_int(7), ctypes.c_ulonglong(99),
+                                               ctypes.c_ulonglong(row_offset), ctypes.c_uint(5), stream_ptr()), "clava_multinomial_step_f32")
+        return out
+    whole = run(0, B, 0)
+    assert torch.equal(whole[1000:2200], run(1000, 2200, 1000))
+    assert int(whole.min()) >= 0 and all(int(whole[:, f].max()) < k for f, k in enumerate(K))

@@ -1,5 +1,7 @@
 set -e
-for m in "" "15" "16" "17" "18" "" "15,128,256" "17,128,256" "16,256,128" "18,256,128"; do
-  echo "small=$m" >> gpurun_out/ab_s.log
-  CLAVA_F16X3_SMALL=$m timeout -k 10 200 python3 tools/bench_chain.py 200 2 >> gpurun_out/ab_s.log 2>&1
+timeout -k 10 600 python -u -m pytest -x -q --timeout 300 --timeout-method thread tests/test_gpu_icdf.py > gpurun_out/t_icdf.log 2>&1 || true
+tail -25 gpurun_out/t_icdf.log
+for m in gumbel icdf; do
+  echo "sampler=$m" >> gpurun_out/ab_icdf.log
+  CLAVA_CAT_SAMPLER=$m timeout -k 10 200 python3 tools/bench_step.py >> gpurun_out/ab_icdf.log 2>&1
 done
