@@ -595,6 +595,10 @@ def main():
                                 "kernel is bound by its 5 transcendentals per class, not by HBM")
         split_nets.set_gemm_mode("f16x3")
         sweep = bench_scale_sweep.measure(batch=4096, train_steps=60, breakdown=True)
+        # how often the float32-level pipelines resolve a Gumbel arg-max differently from exact arithmetic (tools/flip_rate.py:
+        # full batch, 4 teacher-forced steps, injected uniforms, float64 evaluation of the whole step in torch on the GPU)
+        import flip_rate
+        sweep["category_flips_vs_float64"] = flip_rate.measure(batch=4096, steps=4, f64_device=device)
         split_nets.set_gemm_mode(args.gemm)
 
     rows = world * B * args.steps

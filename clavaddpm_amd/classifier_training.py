@@ -388,11 +388,14 @@ class ClassifierTrainer:
             pins = [torch.zeros(nw, dtype=torch.float32).pin_memory() for _ in range(2)]
             lo = B * n + B if on_dev else 0
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # data parallel: the optimizer stays outside (the all-reduce sits between the backward and the update) and the
+            # capture tolerates the process group's watchdog thread (thread-local error mode), as in scripts/train.py
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.dist is not None else "global"):
                 check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self.step_dev), ptr(stage_dev[lo:]),
                                                   c_ll(nw - lo), stream_ptr()), "clava_stage_fetch_f32")
                 out = self._forward_backward(sx, sy32.long(), None)
-                self._adamw_hyper(self.layout.total)
+                if self.dist is None:
+                    self._adamw_hyper(self.layout.total)
             gr = graphs[key] = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
                                 "stage": stage_dev, "hyper": self._hyper_dev,
                                 "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * (B * n + B)) for p in pins]}
@@ -427,15 +430,25 @@ class ClassifierTrainer:
         if not self._flattened:
             self._flatten()
         from . import split_nets
-        if draws is None and self._use_graph and self.dist is None:
-            out = self._graphed(x, labels)
-            if out is not None:                  # the optimizer ran inside the graph
+        out = None
+        if draws is None and self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP", "1") != "0"):
+            try:
+                out = self._graphed(x, labels)
+            except RuntimeError as e:
+                if self.dist is None:
+                    raise
+                import warnings
+                warnings.warn(f"graph capture next to the process group failed ({e}); data-parallel steps stay eager")
+                self._use_graph = False
+                torch.cuda.synchronize()
+            if out is not None and self.dist is None:      # the optimizer ran inside the graph
                 self.opt_step += 1
                 split_nets.invalidate()          # parameters and BatchNorm statistics were rewritten through raw pointers
                 return out
-        x_num, labels = self._inputs(x, labels, draws)
-        out = self._forward_backward(x_num, labels, draws)[:3]
-        self._host_step += 1
+        if out is None:
+            x_num, labels = self._inputs(x, labels, draws)
+            out = self._forward_backward(x_num, labels, draws)[:3]
+            self._host_step += 1
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)

@@ -161,12 +161,24 @@ class Trainer:
                 v.copy_(p.data)
                 p.data = v
         st = self._split_state()
-        # graph replay next to a process group: capture with RCCL's watchdog thread alive is supported by PyTorch, but it has
-        # not been exercised on a multi-GPU MI355X node yet; until then data-parallel runs stay eager unless
-        # CLAVA_TRAIN_GRAPH_DP=1 (the collective is outside the captured region either way)
-        use_graph = self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP") == "1")
+        # Data parallel: the step up to the gradient slabs replays as ONE graph launch (fetch, draws, forward, losses, backward),
+        # then three eager calls: slab reduction into the flat gradient, its all-reduce, AdamW + EMA.  Eager, a step is ~100
+        # host calls for ~0.65 ms of GPU work and every rank would run at the host's pace.  The collective stays OUTSIDE the
+        # captured region; the capture itself uses the thread-local error mode, because the process group's watchdog thread
+        # queries events while this thread captures (under the default global mode such a call invalidates the capture).  A
+        # capture that fails anyway switches this Trainer to eager steps for good (CLAVA_TRAIN_GRAPH_DP=0: never capture).
+        use_graph = self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP", "1") != "0")
         if (st is not None and not st.due() and draws is None and use_graph):
-            done = self._graphed_split_step(x, st)
+            try:
+                done = self._graphed_split_step(x, st)
+            except RuntimeError as e:
+                if self.dist is None:
+                    raise
+                import warnings
+                warnings.warn(f"graph capture next to the process group failed ({e}); data-parallel steps stay eager")
+                self._use_graph = False
+                torch.cuda.synchronize()
+                done = None
             if done is not None and done[2]:                  # the optimizer ran inside the graph
                 return self._loss_pair(done[0], done[1])
             if done is not None:
@@ -305,7 +317,7 @@ class Trainer:
                 st.gather_weights(net.stack()[0][0].detach(), net.stack()[1][0].detach(), d.num_numerical_features)   # allocates
                 st.pack_weights(net.stack()[0], True, dev, gather=True)      # builds the packing plan (an upload: not capturable)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.dist is not None else "global"):
                 st.start_pack(net, d.num_numerical_features + d._sum_k,      # denoiser input width
                               gather_n_num=d.num_numerical_features if gather else None)
                 self._fetch_node(sg)
