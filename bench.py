@@ -477,7 +477,7 @@ def main():
         dom = "gemm_f16x3_256x320" if args.gemm == "f16x3" else "gemm_f32_nt_128x128"
         if dom in families:
             traffic = None
-            for rnd in ("r02", "r01"):                       # newest committed PMC measurement of this kernel
+            for rnd in ("r03", "r02", "r01"):                       # newest committed PMC measurement of this kernel
                 tpath = os.path.join(ROOT, "profiles", f"traffic_{rnd}_f16x3.json" if args.gemm == "f16x3" else f"traffic_{rnd}.json")
                 if os.path.exists(tpath):
                     traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
