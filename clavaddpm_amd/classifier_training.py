@@ -64,7 +64,70 @@ def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=
     return h, mean, invstd
 
 
-def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=None):
+class ClassifierSplitState:
+    """Split-f16 state of one ClassifierTrainer (csrc/split.h; the denoiser's counterpart is training.SplitTrainState).
+
+    The wide blocks of the classifier (input and output width >= 256: 256 -> 512 -> 1024 -> 512 -> 256, 94 % of the step's
+    multiply-adds) run their forward, input-gradient and weight-gradient products on the f16 matrix cores at float32-level
+    accuracy (three f16 MFMAs per product, 22-bit significands); BatchNorm, Dropout, the narrow blocks and the cross
+    entropy stay as they are.  A wide block's input (the previous BatchNorm's output) and its pre-activation gradient are
+    packed into split rows by one launch each; all weights of the wide blocks (W and W^T) by one launch per step.
+    Plane scales come from a float32 step: every `period`-th step runs on the float32 kernels and records the largest
+    magnitude of every weight, block input and gradient; the device overflow flag is read at the same cadence."""
+
+    def __init__(self, period=200):
+        self.period = period
+        self.shift_w = self.shift_h = self.shift_g = None
+        self.since = 0
+        self.flag = None
+        self.generation = 0
+        self.bufs = {}
+        self.plans = {}
+        self.disabled = False
+
+    def due(self):
+        return self.shift_w is None or self.since >= self.period
+
+    @staticmethod
+    def wide(blocks):
+        return [i for i, b in enumerate(blocks) if b[1].in_features >= 256 and b[1].out_features >= 256 and b[1].in_features % 32 == 0]
+
+    def buf(self, key, rows, cols, device):
+        b = self.bufs.get(key + (rows, cols))
+        if b is None:
+            b = self.bufs[key + (rows, cols)] = ops.split_empty(rows, cols, 0, device)
+        return b
+
+    def pack_weights(self, blocks, device):
+        """W (forward operand) and W^T (input-gradient operand) of every wide block, one launch (ops.PackPlan).  Plans are
+        kept per (weight storage, scale): a captured step holds the address of its plan's descriptor table."""
+        idx = self.wide(blocks)
+        key = tuple((i, blocks[i][1].weight.data_ptr(), self.shift_w[i]) for i in idx)
+        plan = self.plans.get(key)
+        if plan is None:
+            items = []
+            for i in idx:
+                w = blocks[i][1].weight.detach()
+                items.append((w, self.shift_w[i], self.buf(("w", i), w.shape[0], w.shape[1], device),
+                              self.buf(("wt", i), w.shape[1], w.shape[0], device)))
+            plan = self.plans[key] = ops.PackPlan(items, device)
+        plan.run(self.flag)
+
+    def calibrate_from(self, stats, idx):
+        """stats: device vector [max |W_i|..., max |block input_i|..., max |dz_i|...] over the wide blocks `idx`."""
+        from .split_nets import TARGET_LOG2, shift_for
+        v = stats.cpu().tolist()                 # the window's one host synchronisation
+        n = len(idx)
+        before = (self.shift_w, self.shift_h, self.shift_g)
+        self.shift_w = {i: shift_for(v[k], 10) for k, i in enumerate(idx)}
+        self.shift_h = {i: shift_for(v[n + k], TARGET_LOG2) for k, i in enumerate(idx)}
+        self.shift_g = {i: shift_for(v[2 * n + k], TARGET_LOG2) for k, i in enumerate(idx)}
+        self.since = 0
+        if before != (self.shift_w, self.shift_h, self.shift_g):
+            self.generation += 1
+
+
+def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=None, split=None):
     """Train-mode `Classifier.forward` keeping what the backward needs.  `keeps`: per-block uint8 [B, C_i] Dropout keep
     masks (parity tests) or None for the in-kernel generator keyed by (seed, step or *step_dev, block)."""
     w0, b0 = clf.time_embed[0].weight.detach(), clf.time_embed[0].bias.detach()
@@ -89,8 +152,18 @@ def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=N
     blocks, _, head = _blocks(clf)
     ws = _bn_workspace(max(b[1].out_features for b in blocks), x_t.device)
     hs, acts, stats = [h], [], []
+    wide = ClassifierSplitState.wide(blocks) if split is not None else []
+    if wide:
+        split.pack_weights(blocks, dev)
+    xsplits = {}
     for i, (j, lin, act, slope, bn, p) in enumerate(blocks):
-        a = ops.linear(hs[-1], lin.weight.detach(), lin.bias.detach(), act="relu" if act == ACT_RELU else "leaky_relu")
+        if i in wide:
+            xs = ops.split_pack(hs[-1], split.shift_h[i], split.flag, out=split.buf(("h", i), B, lin.in_features, dev))
+            a = ops.linear_f16x3(xs, split.buf(("w", i), lin.out_features, lin.in_features, dev), lin.bias.detach(),
+                                 act="relu" if act == ACT_RELU else "leaky_relu", out_f32=True, overflow=split.flag)
+            xsplits[i] = xs
+        else:
+            a = ops.linear(hs[-1], lin.weight.detach(), lin.bias.detach(), act="relu" if act == ACT_RELU else "leaky_relu")
         keep = keeps[i] if keeps is not None else None
         h, mean, invstd = _bn_dropout(a, bn, p, keep, seed, step, step_dev, i, ws, count=False)
         acts.append(a)
@@ -100,7 +173,7 @@ def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=N
     # tiny kernel per layer on the critical chain
     torch._foreach_add_([b[4].num_batches_tracked for b in blocks], 1)
     logits = ops.linear(hs[-1], head.weight.detach(), head.bias.detach())
-    return logits, (x_t, te, z1, a1, hs, acts, stats)
+    return logits, (x_t, te, z1, a1, hs, acts, stats, xsplits)
 
 
 def cross_entropy(logits, labels, want_acc=True):
@@ -123,10 +196,10 @@ def _bn_workspace(C, device):
 
 
 def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, keeps=None, seed=0, step=0, step_dev=None,
-                        splits=_tr.GRAD_SPLITS, side=None):
+                        splits=_tr.GRAD_SPLITS, side=None, split=None, collect=None):
     """Fills `slabs` [splits, layout.total] with the partial gradients of every live parameter for the upstream gradient
     `scale[0] / B` on each row's cross-entropy (`scale`: 0-dim device tensor, the batch-mean loss in the reference)."""
-    x_t, te, z1, a1, hs, acts, stats = saved
+    x_t, te, z1, a1, hs, acts, stats, xsplits = saved
     B, C = logits.shape
     dev = logits.device
     total = layout.total
@@ -170,8 +243,25 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
                                                   c_u32(i), c_int(act), c_float(slope), ptr(ws), c_int(splits), ptr(slabs[:, layout.offsets[gi]:]),
                                                   ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), ptr(dz), c_int(dz.stride(0)),
                                                   stream_ptr()), "clava_bn_dropout_backward_f32")
-        param_grads(f"model.{j}", dz, hs[i])
-        dh = ops.linear_dgrad(dz, lin.weight.detach())
+        if collect is not None:
+            collect[i] = dz.abs().max()
+        if i in xsplits:
+            # wide block on the f16 matrix cores: dz packed once, read by the weight-gradient product (batch-major operands,
+            # bias gradient riding along, on the side stream) and by the input-gradient product
+            dzs = ops.split_pack(dz, split.shift_g[i], split.flag, out=split.buf(("g", i), B, lin.out_features, dev))
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if side is not None:
+                    side.wait_event(ev)
+                wi, bi_ = layout.index[f"model.{j}.weight"], layout.index[f"model.{j}.bias"]
+                ops.linear_wgrad_f16x3_tn(dzs, xsplits[i], splits, slabs[:, layout.offsets[wi]:], total,
+                                          bias_out=slabs[:, layout.offsets[bi_]:])
+            dh = ops.linear_f16x3(dzs, split.buf(("wt", i), lin.in_features, lin.out_features, dev), out_f32=True, overflow=split.flag)
+        else:
+            param_grads(f"model.{j}", dz, hs[i])
+            dh = ops.linear_dgrad(dz, lin.weight.detach())
     g = dh                                             # gradient w.r.t. proj(x) + emb
     param_grads("proj", g, x_t)
     param_grads("time_embed.2", g, a1)
@@ -226,6 +316,8 @@ class ClassifierTrainer:
         self._host_step = 0           # host mirror of step_dev (its parity picks the captured step's pinned input buffer)
         self.history = []
         self._use_graph = os.environ.get("CLAVA_TRAIN_GRAPH", "1") != "0"
+        self.split_with_draws = False     # tests: take the split-f16 path with injected draws too
+        self._window = []
         self._graph = None
         self._side = None
         self._keep = None
@@ -309,7 +401,7 @@ class ClassifierTrainer:
                                             stream_ptr()), "clava_gauss_qsample_f32")
         return x_t, t
 
-    def _forward_backward(self, x_num, labels, draws):
+    def _forward_backward(self, x_num, labels, draws, split=None, collect=None):
         clf = self.classifier
         keeps = None
         if draws is not None and draws.get("keep") is not None:
@@ -321,7 +413,7 @@ class ClassifierTrainer:
                 off += C
         x_t, t = self._noised(x_num, draws)
         B = x_t.shape[0]
-        logits, saved = classifier_forward_train(clf, x_t, t, keeps, self.seed, 0, self.step_dev)
+        logits, saved = classifier_forward_train(clf, x_t, t, keeps, self.seed, 0, self.step_dev, split=split)
         rows, lse, acc1, acc5 = cross_entropy(logits, labels)
         if self._side is None and os.environ.get("CLAVA_TRAIN_STREAMS", "2") != "1":
             self._side = torch.cuda.Stream(device=self.device)
@@ -330,7 +422,7 @@ class ClassifierTrainer:
         a1 = _tr._device_sum(acc1, 1.0 / B, self._side)
         a5 = _tr._device_sum(acc5, 1.0 / B, self._side) if acc5 is not None else None
         self._keep = classifier_backward(clf, saved, logits, labels, lse, loss, self.layout, self.slabs, keeps, self.seed, 0,
-                                         self.step_dev, side=self._side)
+                                         self.step_dev, side=self._side, split=split, collect=collect)
         self.step_dev += 1
         return loss, a1, a5, (saved, logits, rows, lse, acc1, acc5, x_t, t)
 
@@ -362,7 +454,8 @@ class ClassifierTrainer:
         x_num, labels = self._host_inputs(x, labels)
         B, n = x_num.shape
         on_dev = x_num.is_cuda
-        key = (B, n, on_dev)
+        sp = self._split_for(B)
+        key = (B, n, on_dev, sp.generation if sp is not None else -1)     # a captured step bakes the plane scales in
         graphs = self.__dict__.setdefault("_graphs", {})          # one captured step per batch shape (an epoch's short last batch)
         gr = graphs.get(key)
         if gr is None:
@@ -393,7 +486,7 @@ class ClassifierTrainer:
             with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.dist is not None else "global"):
                 check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self.step_dev), ptr(stage_dev[lo:]),
                                                   c_ll(nw - lo), stream_ptr()), "clava_stage_fetch_f32")
-                out = self._forward_backward(sx, sy32.long(), None)
+                out = self._forward_backward(sx, sy32.long(), None, split=sp)
                 if self.dist is None:
                     self._adamw_hyper(self.layout.total)
             gr = graphs[key] = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
@@ -431,6 +524,16 @@ class ClassifierTrainer:
             self._flatten()
         from . import split_nets
         out = None
+        B_ = len(x)
+        sp = self._split_for(B_) if (draws is None or self.split_with_draws) else None
+        calib = sp is not None and sp.due()
+        if sp is not None:
+            self._window.append((x, labels, draws))
+        if calib:
+            self._calibration_step(x, labels, draws, sp)
+            return self._last_out
+        if sp is not None:
+            sp.since += 1
         if draws is None and self._use_graph and (self.dist is None or os.environ.get("CLAVA_TRAIN_GRAPH_DP", "1") != "0"):
             try:
                 out = self._graphed(x, labels)
@@ -447,8 +550,13 @@ class ClassifierTrainer:
                 return out
         if out is None:
             x_num, labels = self._inputs(x, labels, draws)
-            out = self._forward_backward(x_num, labels, draws)[:3]
+            out = self._forward_backward(x_num, labels, draws, split=sp)[:3]
             self._host_step += 1
+        return self._finish_step(out)
+
+    def _finish_step(self, out):
+        """All-reduce (data parallel) and the fused AdamW over the gradient slabs of an eager step."""
+        from . import split_nets
         self.opt_step += 1
         if self.dist is not None:
             _tr.reduce_slabs(self.slabs, 1.0 / self.world, out=self.grad_flat)
@@ -463,6 +571,77 @@ class ClassifierTrainer:
               "clava_adamw_ema_f32")
         split_nets.invalidate()      # parameters and BatchNorm statistics were rewritten through raw pointers
         return out
+
+    # ---- split-f16 products of the wide blocks -----------------------------------------------------------------------------
+    def _split_for(self, B):
+        """The split state when a `B`-row step may use it: split-f16 layer kernels selected (CLAVA_GEMM), whole 32-row blocks
+        for every gradient slab, default LeakyReLU slope (the split kernel's), not switched off after an overflow."""
+        from . import split_nets
+        sp = self.__dict__.get("_split")
+        if sp is None:
+            sp = self._split = ClassifierSplitState(int(os.environ.get("CLAVA_SPLIT_PERIOD", "200")))
+            self._window = []
+            self._snap = None
+            blocks = _blocks(self.classifier)[0]
+            sp.usable = bool(ClassifierSplitState.wide(blocks)) and all(b[2] == ACT_RELU or abs(b[3] - 0.01) < 1e-12 for b in blocks)
+        ok = (sp.usable and not sp.disabled and split_nets.get_gemm_mode() == "f16x3" and os.environ.get("CLAVA_CLF_SPLIT", "1") != "0"
+              and B % 32 == 0 and _tr.wgrad_split_ok(B))
+        return sp if ok else None
+
+    def _state_snapshot(self):
+        clf = self.classifier
+        return {"flat": self.flat.clone(), "m": self.exp_avg.clone(), "v": self.exp_avg_sq.clone(), "opt_step": self.opt_step,
+                "step_dev": self.step_dev.clone(), "host_step": self._host_step,
+                "buffers": [b.detach().clone() for b in clf.buffers()]}
+
+    def _state_restore(self, snap):
+        self.flat.copy_(snap["flat"]); self.exp_avg.copy_(snap["m"]); self.exp_avg_sq.copy_(snap["v"])
+        self.opt_step = snap["opt_step"]
+        self.step_dev.copy_(snap["step_dev"])
+        self._host_step = snap["host_step"]
+        for b, v in zip(self.classifier.buffers(), snap["buffers"]):
+            b.copy_(v)
+        from . import split_nets
+        split_nets.invalidate()
+
+    def _calibration_step(self, x, labels, draws, sp):
+        """Every `period`-th step: read the overflow flag of the window that ends here, then run this step on the float32
+        kernels and take the plane scales of the next window from its tensors.  A raised flag means a magnitude grew more
+        than 60-fold within one window: the window is re-run on the float32 kernels from the snapshot taken at its start
+        (same batches, same Dropout / noise draws: they are keyed by the restored step counter) and the split path stays
+        off for this trainer."""
+        import warnings
+        if sp.flag is None:
+            sp.flag = ops.overflow_flag(self.device)
+        elif int((_par.allreduce_max_(sp.flag.clone()) if self.dist is not None else sp.flag).item()) != 0 and self._snap is not None:
+            warnings.warn("split-f16 classifier training left the float16 range; re-running the window on the float32 kernels")
+            sp.disabled = True
+            self._state_restore(self._snap)
+            window, self._window = self._window, []
+            self.overflow_recoveries = getattr(self, "overflow_recoveries", 0) + 1
+            for (wx, wl, wd) in window:
+                self._last_out = self.step(wx, wl, wd)
+            return
+        self._snap = self._state_snapshot()
+        self._window = [(x, labels, draws)]
+        blocks = _blocks(self.classifier)[0]
+        idx = ClassifierSplitState.wide(blocks)
+        collect = {}
+        x_num, lab = self._inputs(x, labels, draws)
+        out = self._forward_backward(x_num, lab, draws, split=None, collect=collect)
+        self._host_step += 1
+        saved = out[3][0]
+        hs = saved[4]
+        stats = torch.stack([blocks[i][1].weight.detach().abs().max() for i in idx] + [hs[i].abs().max() for i in idx] +
+                            [collect[i] for i in idx])
+        self._last_out = self._finish_step(out[:3])
+        sp.calibrate_from(stats, idx)
+        if len(self.__dict__.get("_graphs", {})) and sp.generation:      # captured steps of older scale generations are dead
+            for k in [k for k in self._graphs if k[3] != sp.generation]:
+                old = self._graphs.pop(k)
+                for ev in old["ev"]:
+                    if ev is not None:
+                        ev.synchronize()
 
     def gradients(self):
         """{name: gradient} of the last step (sum of the slabs), for tests."""

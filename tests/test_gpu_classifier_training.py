@@ -269,3 +269,86 @@ def test_run_loop_learns_separable_clusters(graph, monkeypatch):
     clf.train()
     with pytest.raises(_lib.ClavaHipError, match="labels must lie"):
         tr.step(torch.randn(B, d_in), torch.full((B,), C, dtype=torch.long))
+
+
+def _config_trainer(seed, lr=1e-4):
+    torch.manual_seed(seed)
+    clf = Classifier(d_in=4, d_out=50, dim_t=128, hidden_sizes=[128, 256, 512, 1024, 512, 256, 128]).to(DEV).train()
+    d = GaussianMultinomialDiffusion(np.array([0]), 4, None, num_timesteps=1000, device=torch.device(DEV)).to(DEV)
+    return clf, ct.ClassifierTrainer(clf, d, lr=lr)
+
+
+def test_split_f16_wide_blocks_match_the_float32_kernels_on_injected_draws():
+    """the wide blocks (256 <-> 512 <-> 1024) on the split-f16 kernels.  Same weights, same batch, same
+    injected draws (t, noise, Dropout keep masks) through the float32-kernel step and through the split step (after the
+    float32 calibration step both trainers run): loss 1e-5, every parameter gradient within 1e-4 of its tensor's largest
+    entry (both paths round at float32 level; the oracle pins the float32 path in the G10 tests above)."""
+    from clavaddpm_amd import split_nets
+    B, n, C = 1024, 4, 50
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(B, n, generator=g), torch.randint(0, C, (B,), generator=g)
+    mk = lambda: {"t": torch.randint(0, 1000, (B,), generator=g), "noise": torch.randn(B, n, generator=g),
+                  "keep": (torch.rand(B, 128 + 256 + 512 + 1024 + 512 + 256 + 128, generator=g) < 0.5).to(torch.uint8)}
+    d0, d1 = mk(), mk()
+    prev = split_nets.get_gemm_mode()
+    res = {}
+    try:
+        for mode in ("f32", "f16x3"):
+            split_nets.set_gemm_mode(mode)
+            clf, tr = _config_trainer(11)
+            tr.split_with_draws = True
+            tr.step(x, y, draws=d0)                        # float32 step either way (the split trainer calibrates on it)
+            loss, a1, a5 = tr.step(x, y, draws=d1)
+            sp = tr.__dict__.get("_split")
+            assert (mode == "f16x3") == (sp is not None and sp.shift_w is not None and sp.since == 1)
+            if mode == "f16x3":
+                assert int(sp.flag.item()) == 0
+            res[mode] = (float(loss), float(a1), {k: v.clone() for k, v in tr.gradients().items()}, tr.flat.clone())
+    finally:
+        split_nets.set_gemm_mode(prev)
+    (l0, a0, g0, w0), (l1, a1_, g1, w1) = res["f32"], res["f16x3"]
+    assert abs(l0 - l1) < 1e-5 * abs(l0) and a0 == a1_
+    for k in g0:
+        assert relerr(g1[k], g0[k]) < 1e-4, (k, relerr(g1[k], g0[k]))
+    assert float((w0 - w1).abs().max()) < 2.5e-4            # one AdamW step at lr 1e-4 moves a weight by at most lr: sign flips of ~0 gradients
+
+
+def test_split_f16_classifier_training_runs_captured_and_recalibrates(monkeypatch):
+    """450 steps with a calibration every 100: the loss falls, every non-calibration step replays a captured graph, the
+    overflow flag stays down, and an injected overflow re-runs the window on the float32 kernels from the snapshot."""
+    from clavaddpm_amd import split_nets
+    monkeypatch.setenv("CLAVA_SPLIT_PERIOD", "100")
+    prev = split_nets.get_gemm_mode()
+    split_nets.set_gemm_mode("f16x3")
+    try:
+        clf, tr = _config_trainer(5, lr=1e-3)
+        g = torch.Generator().manual_seed(7)
+        B = 512
+        centres = torch.randn(50, 4, generator=g) * 2
+        def batch():
+            y = torch.randint(0, 50, (B,), generator=g)
+            return centres[y] + 0.3 * torch.randn(B, 4, generator=g), y
+        losses = []
+        for i in range(450):
+            x, y = batch()
+            losses.append(tr.step(x, y)[0])
+        sp = tr._split
+        assert sp.shift_w is not None and not sp.disabled and int(sp.flag.item()) == 0
+        assert len(tr._graphs) >= 1 and tr.opt_step == 450
+        first, last = float(torch.stack(losses[:20]).mean()), float(torch.stack(losses[-20:]).mean())
+        assert np.isfinite(last) and last < 0.9 * first, (first, last)
+        # injected overflow: the next calibration restores the window's start and re-runs it on the float32 kernels
+        w_before_window = tr._snap["flat"].clone()
+        sp.flag.fill_(1)
+        sp.since = sp.period
+        n_window = len(tr._window)
+        with pytest.warns(UserWarning, match="float16 range"):
+            tr.step(*batch())
+        assert sp.disabled and tr.overflow_recoveries == 1
+        assert tr.opt_step == 450 + 1                       # the window was re-run, not added
+        assert bool(torch.isfinite(tr.flat).all()) and not torch.equal(tr.flat, w_before_window)
+        assert tr._split_for(B) is None
+        tr.step(*batch())                                   # continues on the float32 kernels
+        assert tr.opt_step == 452
+    finally:
+        split_nets.set_gemm_mode(prev)
