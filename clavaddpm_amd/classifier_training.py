@@ -29,6 +29,8 @@ from ._lib import ACT_LEAKY, ACT_RELU, c_float, c_int, check, lib, ptr, stream_p
 from .tab_ddpm.modules import timestep_embedding
 
 c_ll = ctypes.c_longlong
+# BatchNorm launches write the split rows the next wide product reads (no packing launch in between); 0: separate packs
+BN_WRITES_SPLIT = os.environ.get("CLAVA_BN_SPLIT", "1") != "0"
 c_u64 = ctypes.c_ulonglong
 c_u32 = ctypes.c_uint
 BN_MOMENTUM = 0.1
@@ -47,18 +49,24 @@ def _blocks(clf):
     return out, j, mods[j]
 
 
-def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=True, count=True):
+def _bn_dropout(a, bn, p, keep, seed, step, step_dev, layer, ws, update_running=True, count=True, split_out=None):
+    """`split_out` = (SplitTensor, shift, overflow flag): the output also goes out as split rows (next block's operand)."""
     B, C = a.shape
     dev = a.device
     mean = torch.empty(C, device=dev, dtype=torch.float32)
     invstd = torch.empty(C, device=dev, dtype=torch.float32)
     h = torch.empty((B, C), device=dev, dtype=torch.float32)
-    check(lib().clava_bn_dropout_train_f32(ptr(a), c_int(a.stride(0)), c_int(B), c_int(C), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+    xs, xsh, xflag = split_out if split_out is not None else (None, 0, None)
+    if xs is not None:
+        xs.shift = xsh
+    check(lib().clava_bn_dropout_train_split_f32(ptr(a), c_int(a.stride(0)), c_int(B), c_int(C), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                                            ptr(bn.running_mean) if update_running else None,
                                            ptr(bn.running_var) if update_running else None, c_float(BN_MOMENTUM if bn.momentum is None else bn.momentum),
                                            c_float(bn.eps), c_float(p), ptr(keep), c_int(keep.stride(0) if keep is not None else 0),
                                            c_u64(seed), c_u32(step), ptr(step_dev), c_u32(layer), ptr(ws), ptr(mean), ptr(invstd),
-                                           ptr(h), c_int(h.stride(0)), stream_ptr()), "clava_bn_dropout_train_f32")
+                                           ptr(h), c_int(h.stride(0)),
+                                                 ptr(xs.buf) if xs is not None else None, c_ll(xs.pitch if xs is not None else 0), c_int(xsh),
+                                                 ptr(xflag), stream_ptr()), "clava_bn_dropout_train_split_f32")
     if update_running and count:
         bn.num_batches_tracked += 1
     return h, mean, invstd
@@ -155,17 +163,23 @@ def classifier_forward_train(clf, x_t, t, keeps=None, seed=0, step=0, step_dev=N
     wide = ClassifierSplitState.wide(blocks) if split is not None else []
     if wide:
         split.pack_weights(blocks, dev)
-    xsplits = {}
+    xsplits, prepacked = {}, {}
     for i, (j, lin, act, slope, bn, p) in enumerate(blocks):
         if i in wide:
-            xs = ops.split_pack(hs[-1], split.shift_h[i], split.flag, out=split.buf(("h", i), B, lin.in_features, dev))
+            xs = prepacked.pop(i, None)            # written by the previous block's BatchNorm launch
+            if xs is None:
+                xs = ops.split_pack(hs[-1], split.shift_h[i], split.flag, out=split.buf(("h", i), B, lin.in_features, dev))
             a = ops.linear_f16x3(xs, split.buf(("w", i), lin.out_features, lin.in_features, dev), lin.bias.detach(),
                                  act="relu" if act == ACT_RELU else "leaky_relu", out_f32=True, overflow=split.flag)
             xsplits[i] = xs
         else:
             a = ops.linear(hs[-1], lin.weight.detach(), lin.bias.detach(), act="relu" if act == ACT_RELU else "leaky_relu")
         keep = keeps[i] if keeps is not None else None
-        h, mean, invstd = _bn_dropout(a, bn, p, keep, seed, step, step_dev, i, ws, count=False)
+        nxt = None
+        if BN_WRITES_SPLIT and i + 1 in wide:
+            nxt = (split.buf(("h", i + 1), B, lin.out_features, dev), split.shift_h[i + 1], split.flag)
+            prepacked[i + 1] = nxt[0]
+        h, mean, invstd = _bn_dropout(a, bn, p, keep, seed, step, step_dev, i, ws, count=False, split_out=nxt)
         acts.append(a)
         stats.append((mean, invstd))
         hs.append(h)
@@ -237,18 +251,24 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
         keep = keeps[i] if keeps is not None else None
         dz = torch.empty_like(a)
         gi, bi = layout.index[f"model.{j + 2}.weight"], layout.index[f"model.{j + 2}.bias"]
-        check(lib().clava_bn_dropout_backward_f32(ptr(dh), c_int(dh.stride(0)), ptr(a), c_int(a.stride(0)), c_int(B), c_int(a.shape[1]),
-                                                  ptr(mean), ptr(invstd), ptr(bn.weight.detach()), c_float(p), ptr(keep),
-                                                  c_int(keep.stride(0) if keep is not None else 0), c_u64(seed), c_u32(step), ptr(step_dev),
-                                                  c_u32(i), c_int(act), c_float(slope), ptr(ws), c_int(splits), ptr(slabs[:, layout.offsets[gi]:]),
-                                                  ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), ptr(dz), c_int(dz.stride(0)),
-                                                  stream_ptr()), "clava_bn_dropout_backward_f32")
+        dzs = None
+        if i in xsplits and BN_WRITES_SPLIT:
+            dzs = split.buf(("g", i), B, lin.out_features, dev)
+            dzs.shift = split.shift_g[i]
+        check(lib().clava_bn_dropout_backward_split_f32(
+            ptr(dh), c_int(dh.stride(0)), ptr(a), c_int(a.stride(0)), c_int(B), c_int(a.shape[1]), ptr(mean), ptr(invstd),
+            ptr(bn.weight.detach()), c_float(p), ptr(keep), c_int(keep.stride(0) if keep is not None else 0), c_u64(seed), c_u32(step),
+            ptr(step_dev), c_u32(i), c_int(act), c_float(slope), ptr(ws), c_int(splits), ptr(slabs[:, layout.offsets[gi]:]),
+            ptr(slabs[:, layout.offsets[bi]:]), c_ll(total), ptr(dz), c_int(dz.stride(0)), ptr(dzs.buf) if dzs is not None else None,
+            c_ll(dzs.pitch if dzs is not None else 0), c_int(dzs.shift if dzs is not None else 0),
+            ptr(split.flag) if dzs is not None else None, stream_ptr()), "clava_bn_dropout_backward_split_f32")
         if collect is not None:
             collect[i] = dz.abs().max()
         if i in xsplits:
             # wide block on the f16 matrix cores: dz packed once, read by the weight-gradient product (batch-major operands,
             # bias gradient riding along, on the side stream) and by the input-gradient product
-            dzs = ops.split_pack(dz, split.shift_g[i], split.flag, out=split.buf(("g", i), B, lin.out_features, dev))
+            if dzs is None:
+                dzs = ops.split_pack(dz, split.shift_g[i], split.flag, out=split.buf(("g", i), B, lin.out_features, dev))
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(main)

@@ -37,6 +37,8 @@ struct BnFwdArgs {
     float p;                          // dropout probability (0: no dropout)
     unsigned long long seed; unsigned int step, layer;
     const unsigned int* step_dev;     // when not null the step index is read from device memory (captured graphs)
+    // optional second copy of h as split rows (csrc/split.h): the operand of the next block's split-f16 product
+    char* xs = nullptr; long long xs_pitch = 0; float xs_scale = 1.f; int* xs_overflow = nullptr;
 };
 
 __device__ __forceinline__ int slab_rows(int B, int S) { return (B + S - 1) / S; }
@@ -61,6 +63,24 @@ __device__ __forceinline__ void store4(float* __restrict__ p, int ld, int r, int
     if (col + 1 < C) q[1] = v.y;
     if (col + 2 < C) q[2] = v.z;
     if (col + 3 < C) q[3] = v.w;
+}
+
+// the same 4 columns as split rows: hi = f16(v * scale), lo = f16(v * scale - hi); 32-column blocks of 64 B hi | 64 B lo
+typedef _Float16 bn_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_split4(char* base, long long pitch, float scale, int* overflow, int r, int col, float4 v) {
+    const float s[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+    bn_h4 hi, lo;
+    bool ovf = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ovf |= !(fabsf(s[i]) <= 65504.f);
+        hi[i] = (_Float16)s[i];
+        lo[i] = (_Float16)(s[i] - (float)hi[i]);
+    }
+    char* p = base + (long long)r * pitch + (long long)(col >> 5) * 128 + ((col & 31) << 1);
+    *reinterpret_cast<bn_h4*>(p) = hi;
+    *reinterpret_cast<bn_h4*>(p + 64) = lo;
+    if (ovf && overflow) *overflow = 1;
 }
 
 // keep flags of the 4 consecutive columns [c4*4, c4*4+4) of row r
@@ -218,6 +238,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnFwdArgs g) {
         o.z = k[2] ? ((v.z - mu.z) * kk.z + be.z) * scale : 0.f;
         o.w = k[3] ? ((v.w - mu.w) * kk.w + be.w) * scale : 0.f;
         store4<VEC>(g.h, g.ldh, r, col, g.C, o);
+        if (g.xs) store_split4(g.xs, g.xs_pitch, g.xs_scale, g.xs_overflow, r, col, o);
     }
 }
 
@@ -233,6 +254,8 @@ struct BnBwdArgs {
     float* dgamma; float* dbeta; long long slab_stride; int splits;   // gradient slabs: slab 0 gets the sum, the others 0
     int act; float slope;             // activation in front of the BatchNorm: act'(a) = a > 0 ? 1 : slope
     float* dz; int lddz;              // [B, C] gradient w.r.t. the Linear output
+    // optional second copy of dz as split rows: the operand of this block's split-f16 input- and weight-gradient products
+    char* xs = nullptr; long long xs_pitch = 0; float xs_scale = 1.f; int* xs_overflow = nullptr;
 };
 
 // grid (ceil(C/128), S): slab sums of dy = dh*keep/(1-p) and of dy*xhat
@@ -341,6 +364,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs g) {
             o.z *= v.z > 0.f ? 1.0f : slope; o.w *= v.w > 0.f ? 1.0f : slope;
         }
         store4<VEC>(g.dz, g.lddz, r, col, g.C, o);
+        if (g.xs) store_split4(g.xs, g.xs_pitch, g.xs_scale, g.xs_overflow, r, col, o);
     }
 }
 
@@ -418,10 +442,28 @@ extern "C" {
 
 long long clava_bn_workspace_floats(int C) { return 2LL * BN_MAX_SLABS * (long long)C; }
 
+int clava_bn_dropout_train_split_f32(const float* a, int lda, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float momentum, float eps, float p, const unsigned char* keep_mask,
+                                     int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev,
+                                     unsigned int layer, float* workspace, float* save_mean, float* save_invstd, float* h, int ldh,
+                                     void* h_split, long long split_pitch, int split_shift, int* overflow, void* stream);
+
 int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, float p, const unsigned char* keep_mask,
                                int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
                                float* workspace, float* save_mean, float* save_invstd, float* h, int ldh, void* stream) {
+    return clava_bn_dropout_train_split_f32(a, lda, B, C, gamma, beta, running_mean, running_var, momentum, eps, p, keep_mask, ldmask, seed,
+                                            step, step_dev, layer, workspace, save_mean, save_invstd, h, ldh, nullptr, 0, 0, nullptr, stream);
+}
+
+int clava_bn_dropout_train_split_f32(const float* a, int lda, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float momentum, float eps, float p, const unsigned char* keep_mask,
+                                     int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev,
+                                     unsigned int layer, float* workspace, float* save_mean, float* save_invstd, float* h, int ldh,
+                                     void* h_split, long long split_pitch, int split_shift, int* overflow, void* stream) {
+    CLAVA_CHECK_ARG(!h_split || (C % 4 == 0 && split_pitch >= 4LL * ((C + 31) & ~31) && split_pitch % 8 == 0 && aligned16(h_split) &&
+                                 split_shift >= -24 && split_shift <= 24),
+                    "bn_dropout_train: the split copy needs C %% 4 == 0 and rows of >= 4*round_up(C,32) bytes");
     CLAVA_CHECK_ARG(a && gamma && beta && workspace && save_mean && save_invstd && h && B > 0 && C > 0 && lda >= C && ldh >= C,
                     "bn_dropout_train: bad arguments");
     CLAVA_CHECK_ARG(p >= 0.f && p < 1.f && (!keep_mask || ldmask >= C) && (!running_mean == !running_var) && layer < 32,
@@ -431,6 +473,9 @@ int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const floa
     g.run_mean = running_mean; g.run_var = running_var; g.momentum = momentum; g.eps = eps; g.save_mean = save_mean;
     g.save_invstd = save_invstd; g.h = h; g.ldh = ldh; g.mask = keep_mask; g.ldmask = ldmask; g.p = p; g.seed = seed; g.step = step;
     g.step_dev = step_dev; g.layer = layer;
+    CLAVA_CHECK_ARG(!h_split || (C % 4 == 0 && split_pitch >= 4LL * ((C + 31) / 32 * 32) && split_pitch % 8 == 0 && aligned16(h_split)),
+                    "bn_dropout_train_split: split rows need C % 4 == 0 and a pitch of at least 4 * roundup32(C) bytes");
+    g.xs = (char*)h_split; g.xs_pitch = split_pitch; g.xs_scale = ldexpf(1.f, split_shift); g.xs_overflow = overflow;
     const bool vec = C % 4 == 0 && lda % 4 == 0 && ldh % 4 == 0 && aligned16(a) && aligned16(h) && aligned16(workspace);
     const dim3 gs((C + BN_COLS - 1) / BN_COLS, g.S), ga((C + BN_COLS - 1) / BN_COLS, (B + BN_ROWS - 1) / BN_ROWS);
     {
@@ -448,11 +493,32 @@ int clava_bn_dropout_train_f32(const float* a, int lda, int B, int C, const floa
     return CLAVA_OK;
 }
 
+int clava_bn_dropout_backward_split_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
+                                        const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
+                                        int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev,
+                                        unsigned int layer, int act, float slope, float* workspace, int splits, float* dgamma_slabs,
+                                        float* dbeta_slabs, long long slab_stride, float* dz, int lddz, void* dz_split,
+                                        long long split_pitch, int split_shift, int* overflow, void* stream);
+
 int clava_bn_dropout_backward_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
                                   const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
                                   int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev, unsigned int layer,
                                   int act, float slope, float* workspace, int splits, float* dgamma_slabs, float* dbeta_slabs,
                                   long long slab_stride, float* dz, int lddz, void* stream) {
+    return clava_bn_dropout_backward_split_f32(dh, lddh, a, lda, B, C, save_mean, save_invstd, gamma, p, keep_mask, ldmask, seed, step,
+                                               step_dev, layer, act, slope, workspace, splits, dgamma_slabs, dbeta_slabs, slab_stride, dz,
+                                               lddz, nullptr, 0, 0, nullptr, stream);
+}
+
+int clava_bn_dropout_backward_split_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
+                                        const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
+                                        int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev,
+                                        unsigned int layer, int act, float slope, float* workspace, int splits, float* dgamma_slabs,
+                                        float* dbeta_slabs, long long slab_stride, float* dz, int lddz, void* dz_split,
+                                        long long split_pitch, int split_shift, int* overflow, void* stream) {
+    CLAVA_CHECK_ARG(!dz_split || (C % 4 == 0 && split_pitch >= 4LL * ((C + 31) & ~31) && split_pitch % 8 == 0 && aligned16(dz_split) &&
+                                  split_shift >= -24 && split_shift <= 24),
+                    "bn_dropout_backward: the split copy needs C %% 4 == 0 and rows of >= 4*round_up(C,32) bytes");
     CLAVA_CHECK_ARG(dh && a && save_mean && save_invstd && gamma && workspace && dgamma_slabs && dbeta_slabs && dz && B > 0 && C > 0 &&
                         lddh >= C && lda >= C && lddz >= C && splits >= 1 && splits <= 64,
                     "bn_dropout_backward: bad arguments");
@@ -462,6 +528,9 @@ int clava_bn_dropout_backward_f32(const float* dh, int lddh, const float* a, int
     g.mean = save_mean; g.invstd = save_invstd; g.gamma = gamma; g.mask = keep_mask; g.ldmask = ldmask; g.p = p; g.seed = seed;
     g.step = step; g.step_dev = step_dev; g.layer = layer; g.dgamma = dgamma_slabs; g.dbeta = dbeta_slabs;
     g.slab_stride = slab_stride; g.splits = splits; g.act = act; g.slope = slope; g.dz = dz; g.lddz = lddz;
+    CLAVA_CHECK_ARG(!dz_split || (C % 4 == 0 && split_pitch >= 4LL * ((C + 31) / 32 * 32) && split_pitch % 8 == 0 && aligned16(dz_split)),
+                    "bn_dropout_backward_split: split rows need C % 4 == 0 and a pitch of at least 4 * roundup32(C) bytes");
+    g.xs = (char*)dz_split; g.xs_pitch = split_pitch; g.xs_scale = ldexpf(1.f, split_shift); g.xs_overflow = overflow;
     const bool vec = C % 4 == 0 && lda % 4 == 0 && lddh % 4 == 0 && lddz % 4 == 0 && aligned16(a) && aligned16(dh) && aligned16(dz) &&
                      aligned16(workspace) && aligned16(save_mean) && aligned16(save_invstd);
     const dim3 gs((C + BN_COLS - 1) / BN_COLS, g.S), ga((C + BN_COLS - 1) / BN_COLS, (B + BN_ROWS - 1) / BN_ROWS);

@@ -536,6 +536,21 @@ int clava_bn_dropout_backward_f32(const float* dh, int lddh, const float* a, int
                                   int act, float slope, float* workspace,
                                   int splits, float* dgamma_slabs, float* dbeta_slabs, long long slab_stride, float* dz,
                                   int lddz, void* stream);
+/* The two entry points above with a second copy of their output as split rows (the number format of clava_gemm_f16x3:
+ * planes scaled by 2^split_shift, rows split_pitch bytes apart, *overflow raised when a scaled magnitude leaves the float16
+ * range), so that the wide blocks' split-f16 products (pipeline_utils.py:607-617 forward; autograd's backward through them)
+ * read their operands without a packing launch in between.  h_split / dz_split == NULL: exactly the calls above. */
+int clava_bn_dropout_train_split_f32(const float* a, int lda, int B, int C, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float momentum, float eps, float p, const unsigned char* keep_mask,
+                                     int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev,
+                                     unsigned int layer, float* workspace, float* save_mean, float* save_invstd, float* h, int ldh,
+                                     void* h_split, long long split_pitch, int split_shift, int* overflow, void* stream);
+int clava_bn_dropout_backward_split_f32(const float* dh, int lddh, const float* a, int lda, int B, int C, const float* save_mean,
+                                        const float* save_invstd, const float* gamma, float p, const unsigned char* keep_mask,
+                                        int ldmask, unsigned long long seed, unsigned int step, const unsigned int* step_dev,
+                                        unsigned int layer, int act, float slope, float* workspace, int splits, float* dgamma_slabs,
+                                        float* dbeta_slabs, long long slab_stride, float* dz, int lddz, void* dz_split,
+                                        long long split_pitch, int split_shift, int* overflow, void* stream);
 /* F.cross_entropy(logits, labels, reduction='none') per row (pipeline_utils.py:683) with the row's logsumexp and the
  * acc@1 / acc@5 indicators of compute_top_k (pipeline_utils.py:640-645; either may be NULL). */
 int clava_cross_entropy_rows_f32(const float* logits, int ld, const long long* labels, int B, int C, float* loss_rows, float* acc1,
