@@ -126,6 +126,27 @@ def test_full_size_chain_matches_float32_kernels():
     assert relerr(out["f16x3"], out["f32"]) < 1e-5
 
 
+def test_mask_bits_give_the_same_input_gradient_as_the_activation_planes(monkeypatch):
+    """The guidance chain hands the wide classifier layers' activation derivatives to the input-gradient products as bits
+    (csrc/split.h `bits_out` / `mask_bits`) instead of re-reading the stored activations: the same 0/1 factors, so the
+    guided samples are bit-identical to CLAVA_MASK_BITS=0 (config classifier widths; ragged row count)."""
+    from weights import classifier_shapes, mlp_shapes, seeded_state
+    dl, cl, n_num, C, T = [512, 1024, 512], [128, 256, 512, 1024, 512, 256, 128], 5, 50, 1000
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(dl), "dropout": 0.0})
+    net.load_state_dict(seeded_state(mlp_shapes(n_num, dl), 3))
+    clf = Classifier(d_in=n_num, d_out=C, dim_t=128, hidden_sizes=cl)
+    clf.load_state_dict(seeded_state(classifier_shapes(n_num, C, cl), 4))
+    d = GaussianMultinomialDiffusion(np.array([0]), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    ys = torch.randint(0, C, (1237, 1), generator=torch.Generator().manual_seed(0))
+    cf = make_cond_fn(clf.to(DEV).eval(), 1.0)
+    out = {}
+    for bits in ("1", "0"):
+        monkeypatch.setenv("CLAVA_MASK_BITS", bits)
+        out[bits], _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, seed=5, n_steps=6)
+    assert torch.isfinite(out["1"]).all()
+    assert torch.equal(out["1"], out["0"])
+
+
 @pytest.mark.parametrize("rows,cols", [(301, 77), (64, 64), (4096, 1024), (33, 130), (1, 5)])
 def test_split_transpose_moves_the_planes_exactly(rows, cols):
     g = _gen(rows + cols)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 rocprofv3 artefacts (run on the GPU box from the repository root): kernel-trace summaries and PMC passes, each
+# Round-3 rocprofv3 artefacts (run on the GPU box from the repository root): kernel-trace summaries and PMC passes, each
 # under its own time limit; stops at the first failure.  Outputs go to gpurun_out/r03/ and are copied into profiles/ by hand.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -21,6 +21,7 @@ CLAVA_CHAIN_STREAMS=1 stats r03_bench_f16x3_serial $B
 stats r03_step_kernels python3 tools/bench_step.py --profile
 MODES=f16x3 stats r03_train_step python3 tools/bench_train.py
 CLAVA_GEMM=f16x3 stats r03_scale_sweep python3 tools/bench_scale_sweep.py
+stats r03_classifier_train python3 tools/bench_classifier_train.py
 pmc gemm FETCH_SIZE python3 tools/pmc_f16x3.py 1024 1024 0
 pmc gemm WRITE_SIZE python3 tools/pmc_f16x3.py 1024 1024 0
 pmc step FETCH_SIZE python3 tools/bench_step.py --profile
