@@ -251,6 +251,16 @@ struct IcdfBlock {
     const float* lg;
 };
 
+// probability-space constants of a block (float32 exp of the reference's float32 log tables)
+__device__ __forceinline__ void icdf_constants(const ScheduleDev& s, int t, float logk, float& A, float& U, float& s_hot, float& s_cold) {
+    const int tp = max(t - 1, 0);
+    A = (t != 0) ? expf(s.log_cumprod_alpha[tp]) : 1.f;
+    U = (t != 0) ? expf(s.log_1_min_cumprod_alpha[tp] - logk) : 0.f;
+    const float la = s.log_alpha[t], un = s.log_1_min_alpha[t] - logk;
+    s_hot = expf(log_add_exp(0.f + la, un));
+    s_cold = expf(log_add_exp(LOG_TINY + la, un));
+}
+
 template <int G, int Q>
 __device__ __forceinline__ int icdf_resident(const IcdfBlock& b, float u, int lane) {
     float v[Q];
@@ -289,14 +299,103 @@ __device__ __forceinline__ int icdf_resident(const IcdfBlock& b, float u, int la
     return key == 0x7fffffff ? (total == total ? b.K - 1 : 0) : (key / Q) + (key % Q) * G;
 }
 
+// One block per wavefront (G = 64), up to 64 Q classes.  Three more things make the per-class work ~10 instructions:
+//  * the hot class's weight is split into its cold-valued part, which sits at the class's place in the order, and the
+//    remainder delta = (p_hot * A + U) * (s_hot - s_cold) >= 0, a piece of its own at the END of the order: the per-class
+//    loop then knows one side factor only, and u * total beyond the cold total simply means "the hot class";
+//  * the cold weights are affine in the softmax numerators e_c: the running sum at (lane, slot j) is
+//    kE * (sum of e up to there) + kU * (number of classes up to there), so ONE prefix sum over the lanes' e totals gives the
+//    softmax sum, the total and every lane's start, and the class count needs no scan (lane-major order, ragged last slot);
+//  * the lane that holds the draw comes from a ballot over the lanes' end sums, the slot inside it from a count of the
+//    running sums below the target, read from that lane.
+// exp = one hardware exp2 of fma(x, log2 e, -max log2 e): 1e-6 relative at worst on classes within e^-20 of the largest,
+// a sampler's weights, not a value any parity test pins.
+template <int Q>
+__device__ __forceinline__ int icdf_wave(const IcdfBlock& b, float u, int lane) {
+    const float LOG2E = 1.44269504088896341f;
+    const int nfull = b.K >> 6, rem = b.K & 63;                 // scalar: whole slots, lanes of the ragged slot
+    float e[Q];
+    float m1 = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int c = lane + j * 64;
+        e[j] = (c < b.K) ? b.lg[c] : -INFINITY;
+        m1 = fmaxf(m1, e[j]);
+    }
+    const float ml = group_max<64>(m1) * LOG2E;
+    const bool hot_ok = b.hot >= 0 && b.hot < b.K;
+    const int hot_slot = b.hot >> 6;                             // (scalar)
+    float pe = 0.f, eh = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {                                // e[j] <- running sum of the lane's numerators
+        const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(e[j], LOG2E, -ml));
+        eh = (j == hot_slot) ? ev : eh;                          // the hot class's numerator stays in its lane (no second load)
+        pe += ev;
+        e[j] = pe;
+    }
+    const float incl = group_scan<64>(pe);
+    const float S = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+    const float kE = b.A * b.s_cold * __builtin_amdgcn_rcpf(S), kU = b.U * b.s_cold;
+    const float cold_total = kE * S + kU * (float)b.K;
+    float delta = 0.f;
+    if (hot_ok) {
+        const float e_hot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eh), b.hot & 63));
+        delta = (e_hot * (b.A * __builtin_amdgcn_rcpf(S)) + b.U) * (b.s_hot - b.s_cold);
+    }
+    const float total = cold_total + delta;
+    if (!(total == total)) return 0;                             // NaN / infinite scores: class 0 (inside the block)
+    const float target = u * total;
+    if (hot_ok && target > cold_total) return b.hot;
+    const int before_n = lane * nfull + min(lane, rem);          // classes owned by the lanes in front
+    const int nv = nfull + (lane < rem ? 1 : 0);
+    const float lane_end = __builtin_fmaf(kE, incl, kU * (float)(before_n + nv));
+    const unsigned long long hit = __ballot(nv > 0 && lane_end >= target);
+    if (hit == 0ull) return b.K - 1;                             // u * total beyond the last sum by rounding
+    const int wl = __builtin_ctzll(hit);
+    // running sum at slot j = kE * (before_e + e[j]) + kU * (before_n + j + 1) = fma(kE, e[j], base + kU * (j + 1))
+    const float base = __builtin_fmaf(kE, incl - pe, kU * (float)before_n);
+    const float thr = target - base;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) cnt += (__builtin_fmaf(kE, e[j], kU * (float)(j + 1)) < thr) ? 1 : 0;
+    const int nv_w = nfull + (wl < rem ? 1 : 0);
+    const int slot = min(__builtin_amdgcn_readlane(cnt, wl), nv_w - 1);
+    return wl + slot * 64;
+}
+
+// the block's uniform in (0, 1]: 24 bits of one Philox word keyed by (seed, global row * m + feature, step)
+__device__ __forceinline__ float icdf_uniform(const MultiStepArgs& a, int row, int f) {
+    const unsigned long long pair_id = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.m + f;
+    const unsigned step_key = a.step_index + (a.step_counter ? *a.step_counter : 0u);
+    const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, pair_id, step_key, clava_rng::STREAM_CAT | (0x1fffffu << 3));
+    return ((float)(r.x >> 8) + 1.0f) * 5.9604644775390625e-8f;
+}
+// the drawn class and, if asked for, the log-one-hot image of the next denoiser input (utils.py:127-134)
 template <int G>
-__device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, const int* s_off, const float* s_logk, bool staged,
-                                                       int row, int f, bool active) {
+__device__ __forceinline__ void icdf_write_g(const MultiStepArgs& a, int row, int f, int o, int K, int best_c, int lane) {
+    if (lane == 0) a.idx_out[(size_t)row * a.m + f] = best_c;
+    if (a.x_in) {
+        float* xo = a.x_in + (size_t)row * a.ld_xin + o;
+        for (int c = lane; c < K; c += G) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
+    }
+    if (a.xs.base)
+        for (int c = lane; c < K; c += G) store_split(a.xs, row, a.xs.col0 + o + c, (c == best_c) ? 0.f : LOG_TINY);
+}
+
+// `s_prob` (staged tables and one t per launch): the block's probability-space constants U, s_hot, s_cold per feature and A
+// at [3 m], evaluated once per workgroup instead of once per block (four exponentials and two log-add-exps: more than the
+// per-class work of a block of up to 64 classes)
+template <int G>
+__device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, const int* s_off, const float* s_logk,
+                                                       const float* s_prob, bool staged, int row, int f, bool active, int hot) {
     const int lane = threadIdx.x & (G - 1);
     if (!active) return;
+    if (G == 64) {      // one block per wavefront: row and feature in scalar registers, so that the addresses, the block's
+        row = __builtin_amdgcn_readfirstlane(row);      // constants and the whole Philox call run on the scalar unit
+        f = __builtin_amdgcn_readfirstlane(f);
+    }
     int o = staged ? s_off[f] : a.offsets[f];
     int K = (staged ? s_off[f + 1] : a.offsets[f + 1]) - o;
-    int hot = a.idx_in[(size_t)row * a.m + f];
     if (G == 64) {
         o = __builtin_amdgcn_readfirstlane(o);
         K = __builtin_amdgcn_readfirstlane(K);
@@ -304,27 +403,22 @@ __device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, c
     }
     const int t = a.t_rows ? (int)a.t_rows[row] : a.t;
     const float logk = staged ? s_logk[f] : a.log_k[f];
-    const int tp = max(t - 1, 0);
     IcdfBlock b;
-    // probability-space constants of the block (float32 exp of the reference's float32 log tables)
-    b.A = (t != 0) ? expf(a.s.log_cumprod_alpha[tp]) : 1.f;
-    b.U = (t != 0) ? expf(a.s.log_1_min_cumprod_alpha[tp] - logk) : 0.f;
-    const float la = a.s.log_alpha[t], un = a.s.log_1_min_alpha[t] - logk;
-    b.s_hot = expf(log_add_exp(0.f + la, un));
-    b.s_cold = expf(log_add_exp(LOG_TINY + la, un));
+    if (s_prob) {
+        b.U = s_prob[3 * f]; b.s_hot = s_prob[3 * f + 1]; b.s_cold = s_prob[3 * f + 2]; b.A = s_prob[3 * a.m];
+    } else {
+        icdf_constants(a.s, t, logk, b.A, b.U, b.s_hot, b.s_cold);
+    }
     b.K = K; b.hot = hot;
     b.lg = a.logits + (size_t)row * a.ld_logits + o;
-    const unsigned long long pair_id = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.m + f;
-    const unsigned step_key = a.step_index + (a.step_counter ? *a.step_counter : 0u);
-    const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, pair_id, step_key, clava_rng::STREAM_CAT | (0x1fffffu << 3));
-    // 24 random bits -> (0, 1]: the search looks for the first running sum >= u * total
-    const float u = ((float)(r.x >> 8) + 1.0f) * 5.9604644775390625e-8f;
+    const float u = icdf_uniform(a, row, f);          // the search looks for the first running sum >= u * total
     int best_c;
-    if (G < 64 || K <= 64) best_c = icdf_resident<G, 1>(b, u, lane);
-    else if (K <= 128) best_c = icdf_resident<G, 2>(b, u, lane);
-    else if (K <= 256) best_c = icdf_resident<G, 4>(b, u, lane);
-    else if (K <= 512) best_c = icdf_resident<G, 8>(b, u, lane);
-    else if (K <= 1024) best_c = icdf_resident<G, 16>(b, u, lane);
+    if (G < 64) best_c = icdf_resident<G, 1>(b, u, lane);
+    else if (K <= 64) best_c = icdf_wave<1>(b, u, lane);
+    else if (K <= 128) best_c = icdf_wave<2>(b, u, lane);
+    else if (K <= 256) best_c = icdf_wave<4>(b, u, lane);
+    else if (K <= 512) best_c = icdf_wave<8>(b, u, lane);
+    else if (K <= 1024) best_c = icdf_wave<16>(b, u, lane);
     else {
         // beyond 1024 classes: 1024-class chunks (16 per lane, lane-strided) streamed three times (maximum, softmax sum, search)
         constexpr int Q = 16, CH = G * Q;
@@ -364,13 +458,7 @@ __device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, c
         }
         if (best_c < 0) best_c = (total == total) ? K - 1 : 0;
     }
-    if (lane == 0) a.idx_out[(size_t)row * a.m + f] = best_c;
-    if (a.x_in) {
-        float* xo = a.x_in + (size_t)row * a.ld_xin + o;
-        for (int c = lane; c < K; c += G) xo[c] = (c == best_c) ? 0.f : LOG_TINY;
-    }
-    if (a.xs.base)
-        for (int c = lane; c < K; c += G) store_split(a.xs, row, a.xs.col0 + o + c, (c == best_c) ? 0.f : LOG_TINY);
+    icdf_write_g<G>(a, row, f, o, K, best_c, lane);
 }
 
 // All (row, feature) blocks of the `n_feat` features listed in `perm`, 64 / G blocks of one row per wavefront work item.
@@ -388,20 +476,40 @@ __device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const
     const int sub = (threadIdx.x & 63) / G;
     int row = (int)(wave0 / W), w = (int)(wave0 - (long long)row * W);
     const int d_row = (int)(n_waves / W), d_w = (int)(n_waves - (long long)d_row * W);
+    if constexpr (ICDF) {
+        // the block's current class (x_t) is fetched one work item ahead: with one exponential per class left, a work item
+        // is a chain of dependent memory round trips (x_t, the logits), and this takes the first one off it
+        int fi = w * PER + sub, f = perm[min(fi, n_feat - 1)];
+        int hot_next = a.idx_in[(size_t)row * a.m + f];
+        while (row < a.B) {
+            const int row_c = row, f_c = f, hot = hot_next;
+            const bool on = fi < n_feat;
+            row += d_row; w += d_w;
+            if (w >= W) { w -= W; ++row; }
+            if (row < a.B) {
+                fi = w * PER + sub; f = perm[min(fi, n_feat - 1)];
+                hot_next = a.idx_in[(size_t)row * a.m + f];
+            }
+            multinomial_block_icdf<G>(a, s_off, s_logk, a.t_rows ? nullptr : s_side, true, row_c, f_c, on, hot);
+        }
+        return;
+    }
     for (; row < a.B; row += d_row, w += d_w) {
         if (w >= W) { w -= W; ++row; if (row >= a.B) break; }
         const int fi = w * PER + sub;
-        if constexpr (ICDF) multinomial_block_icdf<G>(a, s_off, s_logk, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
-        else multinomial_block<G, MODE>(a, s_off, s_logk, s_side, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
+        multinomial_block<G, MODE>(a, s_off, s_logk, s_side, true, row, perm[min(fi, n_feat - 1)], fi < n_feat);
     }
 }
 
 // ICDF: the inverse-CDF sampler (REVERSE only) as a kernel of its own - its register budget differs from the Gumbel form's
+#ifndef CLAVA_ICDF_WAVES
+#define CLAVA_ICDF_WAVES 6          // waves per SIMD the inverse-CDF instantiation is compiled for (experiments: tools/build_variant.py)
+#endif
 template <int MODE, bool ICDF = false>
-__global__ void __launch_bounds__(256, ICDF ? 5 : 1) multinomial_step_kernel(MultiStepArgs a) {
+__global__ void __launch_bounds__(256, ICDF ? CLAVA_ICDF_WAVES : 1) multinomial_step_kernel(MultiStepArgs a) {
     __shared__ int s_off[MAX_LDS_FEATURES + 1];
     __shared__ float s_logk[MAX_LDS_FEATURES];
-    __shared__ float s_side[2 * MAX_LDS_FEATURES];
+    __shared__ float s_side[3 * MAX_LDS_FEATURES + 1];     // Gumbel: log side factors [2 m]; ICDF: U, s_hot, s_cold [3 m] and A
     __shared__ int s_perm[MAX_LDS_FEATURES];       // features ordered by lane-group width
     __shared__ int s_start[5];
     const bool staged = a.m <= MAX_LDS_FEATURES;
@@ -416,7 +524,7 @@ __global__ void __launch_bounds__(256, ICDF ? 5 : 1) multinomial_step_kernel(Mul
         const int d_row = (int)(n_waves / a.m), d_f = (int)(n_waves - (long long)d_row * a.m);
         for (; row < a.B; row += d_row, f += d_f) {
             if (f >= a.m) { f -= a.m; ++row; if (row >= a.B) break; }
-            if constexpr (ICDF) multinomial_block_icdf<64>(a, s_off, s_logk, false, row, f, true);
+            if constexpr (ICDF) multinomial_block_icdf<64>(a, s_off, s_logk, nullptr, false, row, f, true, a.idx_in[(size_t)row * a.m + f]);
             else multinomial_block<64, MODE>(a, s_off, s_logk, s_side, false, row, f, true);
         }
         return;
@@ -425,7 +533,12 @@ __global__ void __launch_bounds__(256, ICDF ? 5 : 1) multinomial_step_kernel(Mul
     for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
         const float logk = a.log_k[i];
         s_logk[i] = logk;
-        if (MODE != MULTI_MODE_INIT && !a.t_rows) {     // one t for the whole launch: the side factors depend on the feature only
+        if (ICDF && !a.t_rows) {
+            float A, U, sh, sc;
+            icdf_constants(a.s, a.t, logk, A, U, sh, sc);
+            s_side[3 * i] = U; s_side[3 * i + 1] = sh; s_side[3 * i + 2] = sc;
+            if (i == 0) s_side[3 * a.m] = A;
+        } else if (MODE != MULTI_MODE_INIT && !a.t_rows) {     // one t for the whole launch: the side factors depend on the feature only
             const int tp = (MODE == MULTI_MODE_QSAMPLE) ? a.t : max(a.t - 1, 0);
             const float la = (MODE == MULTI_MODE_QSAMPLE) ? a.s.log_cumprod_alpha[tp] : a.s.log_alpha[a.t];
             const float un = ((MODE == MULTI_MODE_QSAMPLE) ? a.s.log_1_min_cumprod_alpha[tp] : a.s.log_1_min_alpha[a.t]) - logk;
@@ -614,10 +727,9 @@ extern "C" int clava_categorical_sampler_set(int mode) {
 
 int clava_launch_multinomial_step(const MultiStepArgs& a_in, hipStream_t stream) {
     MultiStepArgs a = a_in;
-    // (measured: 590 vs 678 us at 20000 rows x 50 features of ~165 classes, but 25 vs 22 us on 8 features of ~5 classes: the
-    // inverse CDF only pays on wide blocks; CLAVA_CAT_SAMPLER=icdf_always forces it)
-    a.icdf = (a.mode == MULTI_MODE_REVERSE && !a.uniforms && !a.log_prob && cat_sampler() >= 1 &&
-              (cat_sampler() == 2 || a.sumK >= 32LL * a.m)) ? 1 : 0;
+    // (measured: 334 vs 673 us at 20000 rows x 50 features of ~165 classes, 18.6 vs 22.1 us on 8 features of ~5 classes:
+    // the inverse CDF draws whenever the kernel makes its own noise; modes 1 and 2 are the same since it wins everywhere)
+    a.icdf = (a.mode == MULTI_MODE_REVERSE && !a.uniforms && !a.log_prob && cat_sampler() >= 1) ? 1 : 0;
     CLAVA_CHECK_ARG(a.B > 0 && a.m > 0 && a.sumK > 0, "multinomial_step: empty shape");
     CLAVA_CHECK_ARG(a.idx_out && a.offsets && a.log_k, "multinomial_step: null idx_out/offsets/log_k");
     CLAVA_CHECK_ARG(a.mode == MULTI_MODE_INIT || a.idx_in, "multinomial_step: idx_in required");

@@ -8,6 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 import torch
+from scipy.stats import chi2
 
 pytestmark = pytest.mark.gpu
 
@@ -37,13 +38,14 @@ def _exact_posterior(tb, logits_row, idx_t, t, K):
 @pytest.mark.parametrize("t", [0, 1, 25, 49])
 def test_reverse_step_draws_follow_the_exact_posterior(sampler, t):
     """2^18 rows with the same logits / x_t per (t, feature): class frequencies within 5 sigma of the exact posterior for
-    every class, chi-square over the classes with at least 8 expected draws; features of every lane-group width, a
-    1000-class feature (16 classes per lane), a 1500-class one (streamed in 1024-class chunks) and peaked as well as flat logits."""
-    K, T, B = [2, 5, 13, 40, 300, 1000, 1500], 50, 1 << 18
+    every class, chi-square over the classes with at least 8 expected draws; features of every lane-group width, every
+    classes-per-lane variant of the one-block-per-wavefront form (64, 100, 200, 300, 1000 classes = 1, 2, 4, 8, 16 per lane),
+    a 1500-class feature (streamed in 1024-class chunks) and peaked as well as flat logits."""
+    K, T, B = [2, 5, 13, 40, 64, 100, 200, 300, 1000, 1500], 50, 1 << 18
     rng = np.random.RandomState(11 + t)
     sumK = sum(K)
-    logits_row = (rng.standard_normal(sumK) * np.repeat([0.5, 2.0, 1.0, 3.0, 1.5, 2.5, 2.0], K)).astype(np.float32)
-    idx_t = [1, 3, 12, 0, 150, 999, 1100]
+    logits_row = (rng.standard_normal(sumK) * np.repeat([0.5, 2.0, 1.0, 3.0, 1.0, 2.0, 0.7, 1.5, 2.5, 2.0], K)).astype(np.float32)
+    idx_t = [1, 3, 12, 0, 63, 99, 130, 150, 999, 1100]          # (hot classes in the last lane, the ragged slot, a middle slot)
     net = MLPDiffusion(sumK, 0, "none", {"d_layers": [32, 32], "dropout": 0.0}).to(DEV)
     d = GaussianMultinomialDiffusion(np.array(K), 0, net, num_timesteps=T, device=torch.device(DEV)).to(DEV)
     tb = schedule.tables("cosine", T)
@@ -64,12 +66,13 @@ def test_reverse_step_draws_follow_the_exact_posterior(sampler, t):
         chi = float((((freq[big] - p[big]) * B) ** 2 / (p[big] * B)).sum())
         dof = int(big.sum()) - 1
         if dof >= 2:
-            assert chi < dof + 4.5 * (2 * dof) ** 0.5, (sampler, t, k, chi, dof)
+            # (the exact chi-square quantile: its right tail is much heavier than a normal's at a dozen degrees of freedom)
+            assert chi < chi2.isf(1e-6, dof), (sampler, t, k, chi, dof)
     # a pure function of (seed, step, global row, feature): the same call repeats, another step index draws afresh
     again, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=3)
     other, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=4)
     assert np.array_equal(again.cpu().numpy(), out)
-    assert float((other.cpu().numpy() != out)[:, 4:].mean()) > 0.002       # (a peaked posterior repeats most draws)
+    assert float((other.cpu().numpy() != out)[:, 7:].mean()) > 0.002       # (a peaked posterior repeats most draws)
 
 
 def test_icdf_draws_do_not_depend_on_how_rows_are_cut(sampler):

@@ -7,6 +7,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("CLAVA_LIB_VARIANT"):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _variant  # noqa: F401  (developer A/B builds)
 import numpy as np
 import torch
 
