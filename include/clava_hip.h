@@ -201,8 +201,9 @@ int clava_multinomial_step_counter_f32(const clava_schedule* sched, int mode, in
 /* Sampler of the reverse step's categorical draws when the kernel draws its own noise (uniforms == NULL, log_prob == NULL):
  * 0 = Gumbel arg-max over the K posterior log-probabilities, the reference's construction (log_sample_categorical,
  * tab_ddpm/gaussian_multinomial_diffsuion.py:506-516, called from p_sample :468-472); 1 = inverse CDF of the same posterior
- * p(x_{t-1} | x_t, x0_hat) (:426-455) evaluated in probability space, one uniform per (row, feature) block (default, taken
- * for tables that average >= 32 classes per feature; 2 = for every table; same distribution, other draws).  Injected uniforms always take the Gumbel form.  Returns the previous setting; any other
+ * p(x_{t-1} | x_t, x0_hat) (:426-455) evaluated in probability space, one uniform per (row, feature) block (default; 2 is
+ * accepted as a synonym; same distribution, other draws).  Injected uniforms always take the Gumbel form.  Returns the
+ * previous setting; any other
  * `mode` only queries.  Process-wide; CLAVA_CAT_SAMPLER=gumbel|icdf sets the initial value. */
 int clava_categorical_sampler_set(int mode);
 
