@@ -24,6 +24,8 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 #ifdef CLAVA_GEMM_STAMPS
 // Diagnostic build only (tools/build_variant.py stamps gemm_f16x3.hip -DCLAVA_GEMM_STAMPS; never in the shipped library):
@@ -224,25 +226,41 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
     constexpr int EW = (TN % 2 == 0) ? 8 : 4;               // columns per lane per store
     constexpr int EP = (TN % 2 == 0) ? TN / 2 : TN;         // stores per output row per plane
     const int Np = (g.N + 31) & ~31;
+    const bool ragged = (g.N & 31) != 0;
     const int m_lane = m0 + wm * (BM / WM) + lrow;
     const float slope = g.act == CLAVA_ACT_RELU ? 0.f : (g.act == CLAVA_ACT_LEAKY ? 0.01f : 1.f);
     // float32 rows that start 16-byte aligned take vector stores (nq is a multiple of EW)
     const bool f32_vec = g.out_f32 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out_f32) & 15) == 0;
-    unsigned amax = 0;                                       // max over stored split values of (bits of |value|): NaN > inf > finite
+    // Overflow test: the float16 hi plane of a value beyond the float16 range is +-inf (NaN for NaN), and inf * 0 = NaN:
+    // ovf accumulates hi * 0 with a packed fma, half an instruction per element, and stays 0 unless a plane left the range.
+    f32x2 ovf = {0.f, 0.f};
 
-    auto epilogue = [&](auto has_mask, auto out_mode) {
+    // Per element the epilogue is VALU work (~13 instructions in the first straight-line version: 8.5 us of a 256 x 320
+    // tile's 7.4 + 1.5 us of prologue / epilogue at 160 elements per lane): it now runs on pairs of columns with the packed
+    // float32 instructions (v_pk_fma / v_pk_mul / v_pk_add) and v_cvt_pk_f16_f32, and, when only split rows go out and
+    // alpha == 1 (FOLD), with the output's power-of-two scale folded into the accumulator scale and the bias - exact, since
+    // the activation is positively homogeneous and power-of-two factors commute with rounding: ~5 instructions per element.
+    auto epilogue = [&](auto has_mask, auto out_mode, auto fold_t) {
         constexpr int MASKM = decltype(has_mask)::value;       // 0: none, 1: the activation's planes, 2: derivative bits
         constexpr bool MASK = MASKM == 1;
         constexpr bool SPLIT = decltype(out_mode)::value != 1, F32 = decltype(out_mode)::value != 0;
+        constexpr bool FOLD = decltype(fold_t)::value;
+        const float sa = FOLD ? g.scale_acc * g.scale_out : g.scale_acc;
+        const f32x2 sa2 = {sa, sa}, slope2 = {slope, slope}, zero2 = {0.f, 0.f};
 #pragma unroll
         for (int ip = 0; ip < EP; ++ip) {
             const int it = wn * TN + (EW == 8 ? 2 * ip : ip);    // n-subtile index inside the workgroup tile
             const int nl = 32 * (it >> 1) + 8 * kq + 4 * (it & 1);
             const int nq = n0 + nl;
             if (nq >= Np) continue;
-            float bs[EW];
+            f32x2 bs2[EW / 2];
 #pragma unroll
-            for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(bs + r) = *reinterpret_cast<const f32x4*>(bias_s + nl + r);
+            for (int r = 0; r < EW; r += 4) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + nl + r);
+                bs2[r / 2] = f32x2{b4[0], b4[1]};
+                bs2[r / 2 + 1] = f32x2{b4[2], b4[3]};
+                if (FOLD) { bs2[r / 2] *= g.scale_out; bs2[r / 2 + 1] *= g.scale_out; }
+            }
             const long long col_off = (long long)(nq >> 5) * 128 + ((nq & 31) << 1);
             const bool inside = nq + EW <= g.N;
             h8 mh8[TM];
@@ -268,38 +286,44 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
             for (int j = 0; j < TM; ++j) {
                 const int m = m_lane + j * 16;
                 if (m >= g.M) continue;
-                float v[EW];
+                f32x2 v[EW / 2];
 #pragma unroll
-                for (int r = 0; r < EW; ++r) {
-                    const float a = (EW == 8) ? acc[2 * ip + (r >> 2)][j][r & 3] : acc[ip][j][r & 3];
-                    const float x = a * g.scale_acc + bs[r];
-                    v[r] = fmaxf(x, x * slope);              // relu (slope 0), leaky relu (0.01), identity (1)
+                for (int p = 0; p < EW / 2; ++p) {
+                    const int r = 2 * p;
+                    const f32x4& a4 = (EW == 8) ? acc[2 * ip + (r >> 2)][j] : acc[ip][j];
+                    const f32x2 a2 = {a4[r & 3], a4[(r & 3) + 1]};
+                    const f32x2 x = __builtin_elementwise_fma(a2, sa2, bs2[p]);     // (the scale is a power of two: same bits as mul + add)
+                    const f32x2 y = x * slope2;
+                    v[p] = f32x2{fmaxf(x[0], y[0]), fmaxf(x[1], y[1])};         // relu (slope 0), leaky relu (0.01), identity (1)
                 }
                 if constexpr (MASK) {
 #pragma unroll
                     for (int r = 0; r < EW; ++r) {
                         const float mv = (EW == 8) ? (float)mh8[j][r] : (float)mh4[j][r];
-                        v[r] *= (mv > 0.f) ? 1.f : g.mask_slope;
+                        v[r >> 1][r & 1] *= (mv > 0.f) ? 1.f : g.mask_slope;
                     }
                 }
                 if constexpr (MASKM == 2) {
 #pragma unroll
-                    for (int r = 0; r < EW; ++r) v[r] *= ((mb[j] >> r) & 1u) ? 1.f : g.mask_slope;
+                    for (int r = 0; r < EW; ++r) v[r >> 1][r & 1] *= ((mb[j] >> r) & 1u) ? 1.f : g.mask_slope;
                 }
+                if constexpr (!FOLD) {
 #pragma unroll
-                for (int r = 0; r < EW; ++r) v[r] *= g.alpha;
-                if (!inside) {
+                    for (int p = 0; p < EW / 2; ++p) v[p] *= g.alpha;
+                }
+                if (ragged && !inside) {                     // (uniform `ragged`: N % 32 == 0 has no pad columns to zero)
 #pragma unroll
-                    for (int r = 0; r < EW; ++r) v[r] = (nq + r < g.N) ? v[r] : 0.f;
+                    for (int r = 0; r < EW; ++r) v[r >> 1][r & 1] = (nq + r < g.N) ? v[r >> 1][r & 1] : 0.f;
                 }
                 if constexpr (SPLIT) {
-                    _Float16 hi[EW], lo[EW];
+                    h2 hi[EW / 2], lo[EW / 2];
 #pragma unroll
-                    for (int r = 0; r < EW; ++r) {
-                        const float sc = v[r] * g.scale_out;
-                        amax = max(amax, __float_as_uint(sc) << 1);
-                        hi[r] = (_Float16)sc;
-                        lo[r] = (_Float16)(sc - (float)hi[r]);
+                    for (int p = 0; p < EW / 2; ++p) {
+                        const f32x2 sc = FOLD ? v[p] : v[p] * g.scale_out;
+                        hi[p] = __builtin_convertvector(sc, h2);
+                        const f32x2 back = __builtin_convertvector(hi[p], f32x2);
+                        lo[p] = __builtin_convertvector(sc - back, h2);
+                        ovf = __builtin_elementwise_fma(back, zero2, ovf);
                     }
                     char* op = g.out_split + (long long)m * g.pitchOut + col_off;
                     if constexpr (EW == 8) {
@@ -308,7 +332,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
                         if (g.bits_out) {                // derivative bits of this lane's 8 columns (uniform branch)
                             unsigned b = 0;
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) b |= (hi[r] > (_Float16)0.f ? 1u : 0u) << r;
+                            for (int r = 0; r < 8; ++r) b |= (hi[r >> 1][r & 1] > (_Float16)0.f ? 1u : 0u) << r;
                             g.bits_out[(long long)m * g.pitchBits + (nq >> 3)] = (unsigned char)b;
                         }
                     } else {
@@ -320,11 +344,11 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
                     float* cp = g.out_f32 + (long long)m * g.ldc + nq;
                     if (f32_vec && inside) {                 // 16-byte stores: a lane's EW consecutive columns of one row
 #pragma unroll
-                        for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(cp + r) = f32x4{v[r], v[r + 1], v[r + 2], v[r + 3]};
+                        for (int r = 0; r < EW; r += 4) *reinterpret_cast<f32x4*>(cp + r) = f32x4{v[r / 2][0], v[r / 2][1], v[r / 2 + 1][0], v[r / 2 + 1][1]};
                     } else {
 #pragma unroll
                         for (int r = 0; r < EW; ++r)
-                            if (nq + r < g.N) cp[r] = v[r];
+                            if (nq + r < g.N) cp[r] = v[r >> 1][r & 1];
                     }
                 }
             }
@@ -332,10 +356,12 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
     };
     using std::integral_constant;
     const int mode = g.out_split ? (g.out_f32 ? 2 : 0) : 1;
+    const bool fold = mode == 0 && g.alpha == 1.f;
     auto run = [&](auto mm) {
-        if (mode == 0) epilogue(mm, integral_constant<int, 0>{});
-        else if (mode == 1) epilogue(mm, integral_constant<int, 1>{});
-        else epilogue(mm, integral_constant<int, 2>{});
+        if (fold) epilogue(mm, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+        else if (mode == 0) epilogue(mm, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+        else if (mode == 1) epilogue(mm, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+        else epilogue(mm, integral_constant<int, 2>{}, integral_constant<bool, false>{});
     };
     if constexpr (EW == 8) {
         if (g.mask_bits) run(integral_constant<int, 2>{});
@@ -345,8 +371,8 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
         if (g.mask) run(integral_constant<int, 1>{});
         else run(integral_constant<int, 0>{});
     }
-    // |value| <= 65504 <=> bits(|value|) <= 0x477fe000; infinities and NaNs have larger patterns
-    if (amax > (0x477fe000u << 1) && g.overflow) *g.overflow = 1;
+    const float ovs = ovf[0] + ovf[1];
+    if (!(ovs == ovs) && g.overflow) *g.overflow = 1;
 #ifdef CLAVA_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have left the wave
     if (lane == 0 && blockIdx.x < 4096 && blockIdx.y == 0)
