@@ -29,6 +29,10 @@ from ._lib import ACT_LEAKY, ACT_RELU, c_float, c_int, check, lib, ptr, stream_p
 from .tab_ddpm.modules import timestep_embedding
 
 c_ll = ctypes.c_longlong
+# Batch ranges per weight-gradient product of the classifier step.  Its narrow blocks (128-256 wide) give one product only a
+# handful of output tiles, so the batch ranges are the parallelism: 16 ranges of 256 rows at batch 4096 run those products
+# in half the time of 8 (0.804 vs 0.840 ms per step; 32: 0.826, the optimizer then reads 32 partial gradients).
+GRAD_SPLITS = int(os.environ.get("CLAVA_CLF_GRAD_SPLITS", "16"))
 # BatchNorm launches write the split rows the next wide product reads (no packing launch in between); 0: separate packs
 BN_WRITES_SPLIT = os.environ.get("CLAVA_BN_SPLIT", "1") != "0"
 c_u64 = ctypes.c_ulonglong
@@ -210,7 +214,7 @@ def _bn_workspace(C, device):
 
 
 def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, keeps=None, seed=0, step=0, step_dev=None,
-                        splits=_tr.GRAD_SPLITS, side=None, split=None, collect=None):
+                        splits=GRAD_SPLITS, side=None, split=None, collect=None):
     """Fills `slabs` [splits, layout.total] with the partial gradients of every live parameter for the upstream gradient
     `scale[0] / B` on each row's cross-entropy (`scale`: 0-dim device tensor, the batch-mean loss in the reference)."""
     x_t, te, z1, a1, hs, acts, stats, xsplits = saved
@@ -329,7 +333,7 @@ class ClassifierTrainer:
         self._flatten()
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.slabs = torch.zeros((_tr.GRAD_SPLITS, total), device=dev, dtype=torch.float32)
+        self.slabs = torch.zeros((GRAD_SPLITS, total), device=dev, dtype=torch.float32)
         self.opt_step = 0
         self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)      # Dropout step counter, advanced on the device
@@ -463,14 +467,16 @@ class ClassifierTrainer:
     def _adamw_hyper(self, n):
         """The fused optimizer over the whole flat buffer, step scalars read from `_hyper_dev` (a captured step's form)."""
         check(lib().clava_adamw_ema_hyper_f32(ptr(self.flat), None, ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.slabs),
-                                              c_int(_tr.GRAD_SPLITS), c_ll(self.layout.total), c_float(1.0), c_ll(n), ptr(self._hyper_dev),
+                                              c_int(GRAD_SPLITS), c_ll(self.layout.total), c_float(1.0), c_ll(n), ptr(self._hyper_dev),
                                               ctypes.c_double(0.0), stream_ptr()), "clava_adamw_ema_hyper_f32")
 
     def _graphed(self, x, labels):
         """The whole step (input fetch, draws, forward, loss, backward, optimizer) as ONE hipGraph launch.  Inputs go through
         two pinned host buffers used alternately (parity of the device step counter) and are fetched by the graph's first
         node (`clava_stage_fetch_f32`): no host-synchronous copy sits between two replays (scripts/train.py has the
-        measurements).  Layout of a buffer, in 4-byte words: x_num [B, n] float32 | labels [B] int32 | 8 optimizer scalars."""
+        measurements).  Layout of a buffer, in 4-byte words: x_num [B, n] float32 (+ 1 pad word if odd) | labels [B] int64 |
+        8 optimizer scalars.  (Labels travel as the int64 the loss kernels read: an int32 -> int64 cast node in front of the
+        draws showed up as 40 us of the step's timeline.)"""
         x_num, labels = self._host_inputs(x, labels)
         B, n = x_num.shape
         on_dev = x_num.is_cuda
@@ -493,25 +499,27 @@ class ClassifierTrainer:
                 if getattr(self, "_graph", None) is old:
                     self._graph = None
             dev = self.device
-            nw = B * n + B + 8
+            y0 = (B * n + 1) & ~1                                   # labels start 8-byte aligned
+            h0 = y0 + 2 * B
+            nw = h0 + 8
             stage_dev = torch.zeros(nw, device=dev, dtype=torch.float32)
             sx = stage_dev[:B * n].view(B, n)
-            sy32 = stage_dev[B * n:B * n + B].view(torch.int32)
-            self._hyper_dev = stage_dev[B * n + B:]
+            sy = stage_dev[y0:h0].view(torch.int64)
+            self._hyper_dev = stage_dev[h0:]
             pins = [torch.zeros(nw, dtype=torch.float32).pin_memory() for _ in range(2)]
-            lo = B * n + B if on_dev else 0
+            lo = h0 if on_dev else 0
             graph = torch.cuda.CUDAGraph()
             # data parallel: the optimizer stays outside (the all-reduce sits between the backward and the update) and the
             # capture tolerates the process group's watchdog thread (thread-local error mode), as in scripts/train.py
             with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.dist is not None else "global"):
                 check(lib().clava_stage_fetch_f32(ptr(pins[0][lo:]), ptr(pins[1][lo:]), ptr(self.step_dev), ptr(stage_dev[lo:]),
                                                   c_ll(nw - lo), stream_ptr()), "clava_stage_fetch_f32")
-                out = self._forward_backward(sx, sy32.long(), None, split=sp)
+                out = self._forward_backward(sx, sy, None, split=sp)
                 if self.dist is None:
                     self._adamw_hyper(self.layout.total)
-            gr = graphs[key] = {"key": key, "graph": graph, "x": sx, "y32": sy32, "out": out, "pins": pins, "ev": [None, None],
+            gr = graphs[key] = {"key": key, "graph": graph, "x": sx, "y": sy, "y0": y0, "out": out, "pins": pins, "ev": [None, None],
                                 "stage": stage_dev, "hyper": self._hyper_dev,
-                                "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * (B * n + B)) for p in pins]}
+                                "hyper_host": [(ctypes.c_float * 8).from_address(p.data_ptr() + 4 * h0) for p in pins]}
         else:
             graphs[key] = graphs.pop(key)        # most recently used last
         self._graph = gr
@@ -524,11 +532,11 @@ class ClassifierTrainer:
                                           gr["hyper_host"][par]), "clava_adamw_hyper_f32")
         if on_dev:
             gr["x"].copy_(x_num)
-            gr["y32"].copy_(labels)
+            gr["y"].copy_(labels)
         else:
             pin = gr["pins"][par]
             pin[:B * n].view(B, n).copy_(x_num)
-            pin[B * n:B * n + B].view(torch.int32).copy_(labels)
+            pin[gr["y0"]:gr["y0"] + 2 * B].view(torch.int64).copy_(labels)
         gr["graph"].replay()
         ev = torch.cuda.Event()
         ev.record()
@@ -583,7 +591,7 @@ class ClassifierTrainer:
             _par.allreduce_sum_(self.grad_flat)
             g, S = self.grad_flat, 1
         else:
-            g, S = self.slabs, _tr.GRAD_SPLITS
+            g, S = self.slabs, GRAD_SPLITS
         check(lib().clava_adamw_ema_f32(ptr(self.flat), None, ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(g), c_int(S),
                                         c_ll(self.layout.total), c_float(1.0), c_ll(self.layout.total), ctypes.c_double(self.lr),
                                         ctypes.c_double(self.betas[0]), ctypes.c_double(self.betas[1]), ctypes.c_double(self.eps),
@@ -605,7 +613,7 @@ class ClassifierTrainer:
             blocks = _blocks(self.classifier)[0]
             sp.usable = bool(ClassifierSplitState.wide(blocks)) and all(b[2] == ACT_RELU or abs(b[3] - 0.01) < 1e-12 for b in blocks)
         ok = (sp.usable and not sp.disabled and split_nets.get_gemm_mode() == "f16x3" and os.environ.get("CLAVA_CLF_SPLIT", "1") != "0"
-              and B % 32 == 0 and _tr.wgrad_split_ok(B))
+              and B % 32 == 0 and _tr.wgrad_split_ok(B, GRAD_SPLITS))
         return sp if ok else None
 
     def _state_snapshot(self):

@@ -426,10 +426,20 @@ __global__ void __launch_bounds__(256) ce_grad_kernel(const float* __restrict__ 
     }
 }
 
+// every workgroup of the elementwise kernels folds all slab statistics of its columns again (a chain of Chan updates): the
+// slab count trades parallelism of the reductions against that prologue (CLAVA_BN_SLABS, at most BN_MAX_SLABS)
+int bn_slab_cap() {
+    static const int cap = [] {
+        const char* v = getenv("CLAVA_BN_SLABS");
+        const int c = v ? atoi(v) : BN_MAX_SLABS;
+        return c < 1 ? 1 : (c > BN_MAX_SLABS ? BN_MAX_SLABS : c);
+    }();
+    return cap;
+}
 int pick_slabs(int B, int C) {
     const int colblocks = (C + BN_COLS - 1) / BN_COLS;
     int s = (512 + colblocks - 1) / colblocks;
-    s = min(s, BN_MAX_SLABS);
+    s = min(s, bn_slab_cap());
     s = min(s, max(1, B / 32));
     return max(1, s);
 }

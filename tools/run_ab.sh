@@ -1,5 +1,6 @@
 set -e
-for v in "" old "" old; do
-  CLAVA_LIB_VARIANT=$v timeout -k 10 300 python3 tools/bench_chain.py 2>&1 | tail -1 >> gpurun_out/ab_chain.log
+for s in 128 64 96 128 64; do
+  echo "bn_slabs=$s" >> gpurun_out/ab_bn.log
+  CLAVA_BN_SLABS=$s timeout -k 10 200 python3 tools/bench_classifier_train.py 2>&1 | grep -E "graph=1|batchnorm" >> gpurun_out/ab_bn.log
 done
-cat gpurun_out/ab_chain.log
+cat gpurun_out/ab_bn.log
