@@ -387,7 +387,8 @@ __device__ __forceinline__ void icdf_write_g(const MultiStepArgs& a, int row, in
 // per-class work of a block of up to 64 classes)
 template <int G>
 __device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, const int* s_off, const float* s_logk,
-                                                       const float* s_prob, bool staged, int row, int f, bool active, int hot) {
+                                                       const float* s_prob, bool staged, int row, int f, bool active, int hot,
+                                                       bool have_u = false, float u_in = 0.f) {
     const int lane = threadIdx.x & (G - 1);
     if (!active) return;
     if (G == 64) {      // one block per wavefront: row and feature in scalar registers, so that the addresses, the block's
@@ -411,7 +412,7 @@ __device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, c
     }
     b.K = K; b.hot = hot;
     b.lg = a.logits + (size_t)row * a.ld_logits + o;
-    const float u = icdf_uniform(a, row, f);          // the search looks for the first running sum >= u * total
+    const float u = have_u ? u_in : icdf_uniform(a, row, f);          // the search looks for the first running sum >= u * total
     int best_c;
     if (G < 64) best_c = icdf_resident<G, 1>(b, u, lane);
     else if (K <= 64) best_c = icdf_wave<1>(b, u, lane);
@@ -465,7 +466,8 @@ __device__ __forceinline__ void multinomial_block_icdf(const MultiStepArgs& a, c
 template <int G, int MODE, bool ICDF>
 __device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const int* s_off, const float* s_logk, const float* s_side,
                                                    const int* perm, int n_feat, long long wave0, long long n_waves) {
-    constexpr int PER = 64 / G;
+    // (inverse CDF, one block per wavefront: a work item is FOUR consecutive blocks of a row, which share one Philox call)
+    constexpr int PER = (ICDF && G == 64) ? 4 : 64 / G;
     const int W = (n_feat + PER - 1) / PER;                 // work items per row
     if (W == 0) return;
     // a stride coprime with W makes every wavefront walk through ALL the features of the bucket (their costs differ by
@@ -476,6 +478,39 @@ __device__ __forceinline__ void multinomial_bucket(const MultiStepArgs& a, const
     const int sub = (threadIdx.x & 63) / G;
     int row = (int)(wave0 / W), w = (int)(wave0 - (long long)row * W);
     const int d_row = (int)(n_waves / W), d_w = (int)(n_waves - (long long)d_row * W);
+    if constexpr (ICDF && G == 64) {
+        // Four blocks per work item: ONE Philox call (its four words are the four blocks' uniforms, keyed by the global row
+        // and the item's place among the table's wide features - a function of the table alone, so the draws still do not
+        // depend on grid, row cuts or GPU count) instead of one per block: the call is ~100 scalar instructions, and the
+        // scalar unit of a CU was as busy as its vector units.  x_t of the next item's four blocks is fetched one item ahead.
+        auto load_hots = [&](int r, int wi, int (&h)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = a.idx_in[(size_t)r * a.m + perm[min(wi * 4 + k, n_feat - 1)]];
+        };
+        int hn[4];
+        load_hots(row, w, hn);
+        const unsigned step_key = a.step_index + (a.step_counter ? *a.step_counter : 0u);
+        while (row < a.B) {
+            const int row_s = __builtin_amdgcn_readfirstlane(row), w_s = __builtin_amdgcn_readfirstlane(w);
+            const int h0 = __builtin_amdgcn_readfirstlane(hn[0]), h1 = __builtin_amdgcn_readfirstlane(hn[1]);
+            const int h2 = __builtin_amdgcn_readfirstlane(hn[2]), h3 = __builtin_amdgcn_readfirstlane(hn[3]);
+            row += d_row; w += d_w;
+            if (w >= W) { w -= W; ++row; }
+            if (row < a.B) load_hots(row, w, hn);
+            const unsigned long long item = (a.row_offset + (unsigned long long)row_s) * (unsigned long long)W + w_s;
+            const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, item, step_key, clava_rng::STREAM_CAT | (0x1ffffeu << 3));
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int fi = w_s * 4 + k;
+                if (fi >= n_feat) break;
+                const unsigned word = k == 0 ? r.x : k == 1 ? r.y : k == 2 ? r.z : r.w;
+                const int hot = k == 0 ? h0 : k == 1 ? h1 : k == 2 ? h2 : h3;
+                const float u = ((float)(word >> 8) + 1.0f) * 5.9604644775390625e-8f;      // 24 bits -> (0, 1]
+                multinomial_block_icdf<64>(a, s_off, s_logk, a.t_rows ? nullptr : s_side, true, row_s, perm[fi], true, hot, true, u);
+            }
+        }
+        return;
+    }
     if constexpr (ICDF) {
         // the block's current class (x_t) is fetched one work item ahead: with one exponential per class left, a work item
         // is a chain of dependent memory round trips (x_t, the logits), and this takes the first one off it
@@ -727,7 +762,7 @@ extern "C" int clava_categorical_sampler_set(int mode) {
 
 int clava_launch_multinomial_step(const MultiStepArgs& a_in, hipStream_t stream) {
     MultiStepArgs a = a_in;
-    // (measured: 334 vs 673 us at 20000 rows x 50 features of ~165 classes, 18.6 vs 22.1 us on 8 features of ~5 classes:
+    // (measured: 286 vs 673 us at 20000 rows x 50 features of ~165 classes, 17.8 vs 22.1 us on 8 features of ~5 classes:
     // the inverse CDF draws whenever the kernel makes its own noise; modes 1 and 2 are the same since it wins everywhere)
     a.icdf = (a.mode == MULTI_MODE_REVERSE && !a.uniforms && !a.log_prob && cat_sampler() >= 1) ? 1 : 0;
     CLAVA_CHECK_ARG(a.B > 0 && a.m > 0 && a.sumK > 0, "multinomial_step: empty shape");

@@ -37,7 +37,7 @@ def _exact_posterior(tb, logits_row, idx_t, t, K):
 
 @pytest.mark.parametrize("t", [0, 1, 25, 49])
 def test_reverse_step_draws_follow_the_exact_posterior(sampler, t):
-    """2^18 rows with the same logits / x_t per (t, feature): class frequencies within 5 sigma of the exact posterior for
+    """2^18 rows with the same logits / x_t per (t, feature): class frequencies within 6 sigma of the exact posterior for
     every class, chi-square over the classes with at least 8 expected draws; features of every lane-group width, every
     classes-per-lane variant of the one-block-per-wavefront form (64, 100, 200, 300, 1000 classes = 1, 2, 4, 8, 16 per lane),
     a 1500-class feature (streamed in 1024-class chunks) and peaked as well as flat logits."""
@@ -60,7 +60,9 @@ def test_reverse_step_draws_follow_the_exact_posterior(sampler, t):
         freq = np.bincount(out[:, f], minlength=k) / B
         p = want[f]
         sigma = np.sqrt(p * (1 - p) / B)
-        worst = np.max(np.abs(freq - p) - 5.0 * sigma)      # ~23 000 class frequencies are compared: 5 sigma each
+        # ~4 200 class frequencies per case, 8 cases per sampler: at 5 sigma one of them is expected beyond the bound in
+        # every tenth run of this file (seen when a change of the generator's key moved the draws); 6 sigma: one in 2 500
+        worst = np.max(np.abs(freq - p) - 6.0 * sigma)
         assert worst < 2e-6, (sampler, t, k, worst)
         big = p * B >= 8
         chi = float((((freq[big] - p[big]) * B) ** 2 / (p[big] * B)).sum())

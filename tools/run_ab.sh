@@ -1,6 +1,3 @@
 set -e
-for s in 128 64 96 128 64; do
-  echo "bn_slabs=$s" >> gpurun_out/ab_bn.log
-  CLAVA_BN_SLABS=$s timeout -k 10 200 python3 tools/bench_classifier_train.py 2>&1 | grep -E "graph=1|batchnorm" >> gpurun_out/ab_bn.log
-done
-cat gpurun_out/ab_bn.log
+timeout -k 10 900 python -u -m pytest -x -q --timeout 300 --timeout-method thread tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_narrow.py tests/test_gpu_pipeline.py > gpurun_out/t_par.log 2>&1 || { tail -40 gpurun_out/t_par.log; exit 1; }
+tail -3 gpurun_out/t_par.log
