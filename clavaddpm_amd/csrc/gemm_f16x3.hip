@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
     constexpr int EW = (TN % 2 == 0) ? 8 : 4;               // columns per lane per store
     constexpr int EP = (TN % 2 == 0) ? TN / 2 : TN;         // stores per output row per plane
     const int Np = (g.N + 31) & ~31;
-    const bool ragged = (g.N & 31) != 0;
+    const bool ragged = (g.N & 31) != 0 && n0 + BN > g.N;     // (uniform) only the last column tile has pad columns to zero
     const int m_lane = m0 + wm * (BM / WM) + lrow;
     const float slope = g.act == CLAVA_ACT_RELU ? 0.f : (g.act == CLAVA_ACT_LEAKY ? 0.01f : 1.f);
     // float32 rows that start 16-byte aligned take vector stores (nq is a multiple of EW)
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) gemm_f16x3_kernel(SplitGemmArgs 
 #pragma unroll
                     for (int p = 0; p < EW / 2; ++p) v[p] *= g.alpha;
                 }
-                if (ragged && !inside) {                     // (uniform `ragged`: N % 32 == 0 has no pad columns to zero)
+                if (ragged && !inside) {                     // (uniform `ragged`: elsewhere there are no pad columns to zero)
 #pragma unroll
                     for (int r = 0; r < EW; ++r) v[r >> 1][r & 1] = (nq + r < g.N) ? v[r >> 1][r & 1] : 0.f;
                 }
