@@ -1,6 +1,6 @@
 set -e
-timeout -k 10 1100 python -u -m pytest -x -q --timeout 300 --timeout-method thread tests -m gpu > gpurun_out/t_full.log 2>&1 || { tail -40 gpurun_out/t_full.log; exit 1; }
-tail -3 gpurun_out/t_full.log
-timeout -k 10 120 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
-timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_r03c.log 2> gpurun_out/bench_r03c.err
-tail -c 300 gpurun_out/bench_r03c.log
+for args in "1024 1024 0" "512 1024 4" "256 512 1" "128 256 -1"; do
+  echo "== N K cfg: $args" >> gpurun_out/stamps.log
+  CLAVA_LIB_VARIANT=stamps timeout -k 10 120 python3 tools/dbg_gemm_stamps.py $args >> gpurun_out/stamps.log 2>&1 || true
+done
+cat gpurun_out/stamps.log
