@@ -153,6 +153,15 @@ int check_split_net(const clava_split_net* n, bool need_grad, const char* who) {
 }
 
 // forward of a split stack: outs[l] (split rows, shift_out[l]) for l < n-1, last layer to float32 `last` (ld_last)
+#define CLAVA_CHECK_HIP(call, what)                                                        \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            clava_set_error("%s: %s", what, hipGetErrorString(e_));                        \
+            return CLAVA_ERR_LAUNCH;                                                       \
+        }                                                                                  \
+    } while (0)
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -193,8 +202,12 @@ int split_net_forward(const clava_split_net* net, const char* x, int M, const fl
 
 // input gradient of a split stack: dlast = split rows (shift_dlast) of d/d(last output); grads[l] (split rows,
 // shift_grad[l]) = d/d(pre-activation of layer l-1) for l >= 1; gx = alpha * d/d(input), float32 [M, dims[0]]
+// `fuse` (the Gaussian reverse step that consumes gx as its guidance gradient): when the last product runs on the
+// memory-bound narrow kernel, the step is done by that launch (after `wait_before_last`, the event behind which the
+// denoiser's eps is complete) and *fused is set
 int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, const char* dlast, char* const* grads, float* gx,
-                         int ld_gx, float alpha, int* overflow, hipStream_t st, unsigned char* const* bits = nullptr) {
+                         int ld_gx, float alpha, int* overflow, hipStream_t st, unsigned char* const* bits = nullptr,
+                         const GaussStepArgs* fuse = nullptr, hipEvent_t wait_before_last = nullptr, bool* fused = nullptr) {
     const char* gin = dlast;
     int shift_g = net->shift_dlast;
     for (int l = net->n_layers - 1; l >= 0; --l) {
@@ -215,7 +228,14 @@ int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, c
         g.out_split = (l == 0) ? nullptr : grads[l]; g.pitchOut = split_pitch(net->dims[l]);
         g.out_f32 = (l == 0) ? gx : nullptr; g.ldc = ld_gx;
         g.overflow = overflow; g.tiles_m = g.tiles_n = 0;
-        int rc = clava_launch_gemm_f16x3(g, -1, st);
+        int rc;
+        if (l == 0 && fuse && env_int("CLAVA_NARROW_SPLIT", 1) != 0 && clava_narrow_split_ok(g)) {
+            if (wait_before_last) CLAVA_CHECK_HIP(hipStreamWaitEvent(st, wait_before_last, 0), "guidance: wait for the denoiser");
+            rc = clava_launch_narrow_split_gauss(g, *fuse, st);
+            if (fused) *fused = true;
+        } else {
+            rc = clava_launch_gemm_f16x3(g, -1, st);
+        }
         if (rc) return rc;
         gin = grads[l];
         shift_g = (l == 0) ? 0 : net->shift_grad[l];
@@ -403,14 +423,6 @@ StreamPool* stream_pool(int dev, hipStream_t caller) {
 }
 
 
-#define CLAVA_CHECK_HIP(call, what)                                                        \
-    do {                                                                                   \
-        hipError_t e_ = (call);                                                            \
-        if (e_ != hipSuccess) {                                                            \
-            clava_set_error("%s: %s", what, hipGetErrorString(e_));                        \
-            return CLAVA_ERR_LAUNCH;                                                       \
-        }                                                                                  \
-    } while (0)
 
 int check_split_chain(const clava_chain* c, const clava_split_net* d, const clava_split_net* k, int B) {
     CLAVA_CHECK_ARG(c && B > 0, "sample_chain_f16x3: null descriptor or empty batch");
@@ -694,7 +706,14 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 rc = clava_launch_split_pack(x_in, D, R, D, d->shift_in, x_split, split_pitch(D), overflow, G.den);
                 if (rc) return rc;
             }
-            if (G.cls != G.den) {
+            // Gaussian step inside the guidance's last launch (narrow_split_gauss): the guidance stream, the step's critical
+            // path, then runs from step to step without a hand-over; the denoiser stream waits for it once per step
+            // (eligibility of the guidance's last product for the narrow kernel, narrow.hip: <= 16 outputs, W within 64 KB of LDS)
+            const bool fuse_gauss = k && G.cls != G.den && c->n_num > 0 && c->m == 0 && !den_fused && !cls_fused && !cat_gather &&
+                                    k->dims[0] == c->n_num && c->n_num <= 16 &&
+                                    (long long)c->n_num * ((k->dims[1] + 31) & ~31) <= 16384 && env_int("CLAVA_NARROW_SPLIT", 1) != 0 &&
+                                    env_int("CLAVA_FUSE_GAUSS", 1) != 0;
+            if (G.cls != G.den && (s == 0 || !fuse_gauss)) {
                 CLAVA_CHECK_HIP(hipEventRecord(pool->fork[gi], G.den), "sample_chain_f16x3: step fork");
                 CLAVA_CHECK_HIP(hipStreamWaitEvent(G.cls, pool->fork[gi], 0), "sample_chain_f16x3: step fork");
             }
@@ -737,6 +756,29 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, ldm, overflow, G.den);
                 if (rc) return rc;
             }
+            // ---- the fused Gaussian step's arguments (it writes float(x_next) straight into the next denoiser input)
+            GaussStepArgs gs;
+            bool gauss_done = false;
+            if (c->n_num > 0) {
+                gs.s = c->sched; gs.B = R; gs.n_num = c->n_num;
+                gs.eps = model_out; gs.ld_eps = ldm;
+                gs.x = x + (size_t)r0 * c->n_num;
+                gs.grad = k ? w.gx + (size_t)r0 * c->n_num : nullptr; gs.ld_grad = c->n_num;
+                gs.noise = c->noise ? c->noise + ((size_t)s * B + r0) * c->n_num : nullptr;
+                gs.x_in = nullptr; gs.ld_xin = 0;
+                if (cat_gather) {                  // the gather layer reads the float32 numeric columns themselves
+                    gs.x_in = w.x_in + (size_t)r0 * c->n_num; gs.ld_xin = c->n_num;
+                } else {
+                    gs.xs.base = x_split; gs.xs.pitch = split_pitch(D); gs.xs.scale = ldexpf(1.f, d->shift_in); gs.xs.col0 = 0;
+                    gs.xs.overflow = overflow;
+                }
+                gs.pred_xstart = nullptr;
+                gs.t_rows = nullptr; gs.t = t;
+                gs.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
+                gs.seed = c->seed; gs.row_offset = c->row_offset + (unsigned long long)r0; gs.step_index = step_index;
+            }
+            if (fuse_gauss)                        // the denoiser's eps is complete behind this event
+                CLAVA_CHECK_HIP(hipEventRecord(pool->fork[gi], G.den), "sample_chain_f16x3: denoiser done");
             // ---- guidance: grad_x log p(y | x_t), on the group's second stream
             const float* grad = nullptr;
             if (k) {
@@ -812,7 +854,8 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                                            dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), R, C);
                         CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
                     }
-                    rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st, cls_bits);
+                    rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st, cls_bits,
+                                              fuse_gauss ? &gs : nullptr, fuse_gauss ? pool->fork[gi] : nullptr, &gauss_done);
                     if (rc) return rc;
                 }
                 grad = gx;
@@ -821,25 +864,13 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     CLAVA_CHECK_HIP(hipStreamWaitEvent(G.den, pool->join[gi], 0), "sample_chain_f16x3: step join");
                 }
             }
-            // ---- fused Gaussian step (writes float(x_next) straight into the next denoiser input)
-            if (c->n_num > 0) {
-                GaussStepArgs g;
-                g.s = c->sched; g.B = R; g.n_num = c->n_num;
-                g.eps = model_out; g.ld_eps = ldm;
-                g.x = x + (size_t)r0 * c->n_num;
-                g.grad = grad; g.ld_grad = c->n_num;
-                g.noise = c->noise ? c->noise + ((size_t)s * B + r0) * c->n_num : nullptr;
-                g.x_in = nullptr; g.ld_xin = 0;
-                if (cat_gather) {                  // the gather layer reads the float32 numeric columns themselves
-                    g.x_in = w.x_in + (size_t)r0 * c->n_num; g.ld_xin = c->n_num;
-                } else {
-                    g.xs.base = x_split; g.xs.pitch = split_pitch(D); g.xs.scale = ldexpf(1.f, d->shift_in); g.xs.col0 = 0;
-                    g.xs.overflow = overflow;
-                }
-                g.pred_xstart = nullptr;
-                g.t_rows = nullptr; g.t = t;
-                g.x_is_f32 = (s == 0 && c->first_step_f32) ? 1 : 0;
-                g.seed = c->seed; g.row_offset = c->row_offset + (unsigned long long)r0; g.step_index = step_index;
+            // ---- fused Gaussian step (unless the guidance's last launch did it)
+            if (fuse_gauss && !gauss_done) {   // the step's stream order above relied on it
+                clava_set_error("sample_chain_f16x3: the guidance's last product did not take the fused Gaussian step (CLAVA_FUSE_GAUSS=0 avoids it)");
+                return CLAVA_ERR_ARG;
+            }
+            if (c->n_num > 0 && !gauss_done) {
+                const GaussStepArgs& g = gs;
                 if (den_fused) {               // the head's eps goes from the accumulators straight into the step
                     FusedHeadArgs ha;
                     ha.stream = (const char*)d->fs_head;

@@ -13,6 +13,7 @@
 #include "clava_hip.h"
 #include "common.h"
 #include "split.h"
+#include "step.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -219,8 +220,11 @@ __global__ void __launch_bounds__(256) narrow_wgrad_kernel(const float* __restri
 // (split.h): the denoiser head and the last input-gradient product of the guidance classifier in the SAMPLING chain.  On
 // the tiled MFMA kernel these use a 64-column tile for 2 useful columns and 157 workgroups walking K in 32-deep blocks
 // (26 us at 20000 rows); here 16 lanes read a row's planes once (4 * Kp bytes), hi + lo is exact in float32, plain FMAs.
-template <int DM>
-__global__ void __launch_bounds__(256) narrow_split_kernel(SplitGemmArgs g) {
+// GAUSS: the product is the guidance gradient of a reverse step (its last input-gradient product) and the row's fused
+// Gaussian posterior step (step.h: gauss_step_element, the body of gauss_step_kernel) follows in the same thread - one launch
+// and one cross-stream hand-over less per reverse step (`ga.grad` = this product's output, `ga.eps` = the denoiser's).
+template <int DM, bool GAUSS>
+__global__ void __launch_bounds__(256) narrow_split_kernel(SplitGemmArgs g, GaussStepArgs ga) {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [N][Kp], hi + lo
     const int Kp = g.Kp, D = g.N;
     for (int i = threadIdx.x; i < D * (Kp >> 2); i += 256) {
@@ -267,6 +271,11 @@ __global__ void __launch_bounds__(256) narrow_split_kernel(SplitGemmArgs g) {
                 g.out_f32[row * g.ldc + d] = g.alpha * (acc[d] * g.scale_acc + b);
             }
         }
+        if constexpr (GAUSS) {
+#pragma unroll
+            for (int d = 0; d < DM; ++d)
+                if (d < D) gauss_step_element(ga, (int)row, d, ga.eps[(size_t)row * ga.ld_eps + d]);    // (reads the gradient this thread just stored)
+        }
     }
 }
 
@@ -290,8 +299,22 @@ int clava_launch_narrow_split(const SplitGemmArgs& g, hipStream_t stream) {
     CLAVA_CHECK_ARG(clava_narrow_split_ok(g) && g.M > 0 && g.Kp > 0 && g.Kp % 32 == 0 && g.ldc >= g.N, "narrow_split: unsupported product");
     ProfScope prof(PROF_MISC, 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp), 4.0 * g.M * ((double)g.Kp + g.N), stream);
     return by_width(g.N, [&](auto dm) {
-        hipLaunchKernelGGL((narrow_split_kernel<decltype(dm)::value>), dim3((g.M + 15) / 16), dim3(256), (size_t)g.N * g.Kp * 4, stream, g);
+        hipLaunchKernelGGL((narrow_split_kernel<decltype(dm)::value, false>), dim3((g.M + 15) / 16), dim3(256), (size_t)g.N * g.Kp * 4, stream, g,
+                           GaussStepArgs{});
         CLAVA_CHECK_LAUNCH("narrow_split");
+        return (int)CLAVA_OK;
+    });
+}
+
+// the same product followed, row by row, by the Gaussian reverse step that consumes it as its guidance gradient
+int clava_launch_narrow_split_gauss(const SplitGemmArgs& g, const GaussStepArgs& ga, hipStream_t stream) {
+    CLAVA_CHECK_ARG(clava_narrow_split_ok(g) && g.M > 0 && g.Kp > 0 && g.Kp % 32 == 0 && g.ldc >= g.N, "narrow_split_gauss: unsupported product");
+    CLAVA_CHECK_ARG(ga.B == g.M && ga.n_num == g.N && ga.grad == g.out_f32 && ga.ld_grad == g.ldc && ga.eps && ga.x,
+                    "narrow_split_gauss: the step's gradient must be this product's output, one column per numeric column");
+    ProfScope prof(PROF_MISC, 2.0 * g.M * g.N * (double)(g.K > 0 ? g.K : g.Kp), 4.0 * g.M * ((double)g.Kp + g.N) + 24.0 * g.M * g.N, stream);
+    return by_width(g.N, [&](auto dm) {
+        hipLaunchKernelGGL((narrow_split_kernel<decltype(dm)::value, true>), dim3((g.M + 15) / 16), dim3(256), (size_t)g.N * g.Kp * 4, stream, g, ga);
+        CLAVA_CHECK_LAUNCH("narrow_split_gauss");
         return (int)CLAVA_OK;
     });
 }

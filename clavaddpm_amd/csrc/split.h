@@ -63,6 +63,8 @@ int clava_gemm_f16x3_config_count();
 // never)
 bool clava_narrow_split_ok(const SplitGemmArgs& g);
 int clava_launch_narrow_split(const SplitGemmArgs& g, hipStream_t stream);
+struct GaussStepArgs;
+int clava_launch_narrow_split_gauss(const SplitGemmArgs& g, const GaussStepArgs& ga, hipStream_t stream);
 // weight-gradient product from batch-major operands (gemm_f16x3_tn.hip): A = dy [Kp rows = batch][M = n_out columns],
 // W = x [Kp][N = k_in], out_f32[n_out][k_in] (slabs over the batch axis as above)
 int clava_launch_gemm_f16x3_tn(SplitGemmArgs g, hipStream_t stream);

@@ -147,6 +147,28 @@ def test_mask_bits_give_the_same_input_gradient_as_the_activation_planes(monkeyp
     assert torch.equal(out["1"], out["0"])
 
 
+def test_gaussian_step_inside_the_guidance_s_last_launch_changes_no_bit(monkeypatch):
+    """The guided chain runs the Gaussian posterior step inside the launch that produces its guidance gradient
+    (narrow_split_gauss: one launch and one cross-stream hand-over less per step; CLAVA_FUSE_GAUSS=0: separate launch on the
+    denoiser stream).  Same element function, same inputs: identical samples, with in-kernel and with injected noise."""
+    from weights import classifier_shapes, mlp_shapes, seeded_state
+    dl, cl, n_num, C, T = [512, 1024, 512], [128, 256, 512, 1024, 512, 256, 128], 5, 50, 1000
+    net = MLPDiffusion(n_num, 0, "none", {"d_layers": list(dl), "dropout": 0.0})
+    net.load_state_dict(seeded_state(mlp_shapes(n_num, dl), 3))
+    clf = Classifier(d_in=n_num, d_out=C, dim_t=128, hidden_sizes=cl)
+    clf.load_state_dict(seeded_state(classifier_shapes(n_num, C, cl), 4))
+    d = GaussianMultinomialDiffusion(np.array([0]), n_num, net.to(DEV).eval(), num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    ys = torch.randint(0, C, (1237, 1), generator=torch.Generator().manual_seed(0))
+    cf = make_cond_fn(clf.to(DEV).eval(), 1.0)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CLAVA_FUSE_GAUSS", fuse)
+        out[fuse], _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, seed=5, n_steps=7)
+    assert torch.isfinite(out["1"]).all()
+    assert torch.equal(out["1"], out["0"])
+    assert not torch.equal(out["1"], d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, seed=6, n_steps=7)[0])
+
+
 @pytest.mark.parametrize("rows,cols", [(301, 77), (64, 64), (4096, 1024), (33, 130), (1, 5)])
 def test_split_transpose_moves_the_planes_exactly(rows, cols):
     g = _gen(rows + cols)
