@@ -7,11 +7,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$NAME
 mkdir -p $O
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 \
-  --no-cpu-baseline --train-steps 0 --no-f32-leg --no-gmm --clf-train-steps 0 --no-scale-sweep > $O.log 2>&1
+  --no-cpu-baseline --train-steps 0 --no-f32-leg --no-gmm --clf-train-steps 0 --no-scale-sweep --no-t2000 > $O.log 2>&1
 T=$(ls $O/*/p_kernel_trace.csv $O/p_kernel_trace.csv 2>/dev/null | head -1)
 S=$(ls $O/*/p_kernel_stats.csv $O/p_kernel_stats.csv 2>/dev/null | head -1)
-python3 tools/trace_timeline.py $T 700 gauss_step_kernel > gpurun_out/${NAME}_timeline.txt
-python3 tools/trace_timeline.py $T 701 gauss_step_kernel >> gpurun_out/${NAME}_timeline.txt
+# the step's last kernel: the guidance's last product with the Gaussian step inside (two streams), gauss_step_kernel (one stream)
+M=${MARKER:-"narrow_split_kernel<2, true>"}
+python3 tools/trace_timeline.py $T 700 "$M" > gpurun_out/${NAME}_timeline.txt
+python3 tools/trace_timeline.py $T 701 "$M" >> gpurun_out/${NAME}_timeline.txt
 cp $S gpurun_out/${NAME}_kernel_stats.csv
 rm -rf $O
 echo done

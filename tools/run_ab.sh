@@ -1,7 +1,16 @@
 set -e
-timeout -k 10 900 python -u -m pytest -x -q --timeout 300 --timeout-method thread tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_f16x3.py tests/test_gpu_narrow.py tests/test_gpu_pipeline.py > gpurun_out/t_par.log 2>&1 || { tail -40 gpurun_out/t_par.log; exit 1; }
-tail -2 gpurun_out/t_par.log
-for v in 1 0 1 0; do
-  CLAVA_FUSE_GAUSS=$v timeout -k 10 300 python3 tools/bench_chain.py 2>&1 | tail -1 | sed "s/^/fuse_gauss=$v /" >> gpurun_out/ab_chain.log
-done
-cat gpurun_out/ab_chain.log
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r03
+mkdir -p $O
+stats() {
+  local name=$1; shift
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/$name -o p --output-format csv -- "$@" > $O/$name.log 2>&1
+  cp $O/$name/p_kernel_stats.csv $O/${name}_kernel_stats.csv
+  rm -rf $O/$name
+}
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --train-steps 0 --no-f32-leg --no-gmm --clf-train-steps 0 --no-scale-sweep --no-t2000"
+stats r03_bench_f16x3 $B
+CLAVA_CHAIN_STREAMS=1 stats r03_bench_f16x3_serial $B
+stats r03_classifier_train python3 tools/bench_classifier_train.py
+bash tools/collect_chain_timeline.sh chain_r03c > /dev/null 2>&1
+head -30 gpurun_out/chain_r03c_timeline.txt
