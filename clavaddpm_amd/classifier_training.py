@@ -33,6 +33,7 @@ c_ll = ctypes.c_longlong
 # handful of output tiles, so the batch ranges are the parallelism: 16 ranges of 256 rows at batch 4096 run those products
 # in half the time of 8 (0.804 vs 0.840 ms per step; 32: 0.826, the optimizer then reads 32 partial gradients).
 GRAD_SPLITS = int(os.environ.get("CLAVA_CLF_GRAD_SPLITS", "16"))
+CLF_WGRAD_STREAMS = int(os.environ.get("CLAVA_CLF_WGRAD_STREAMS", "2"))     # streams the weight-gradient products take turns on
 # BatchNorm launches write the split rows the next wide product reads (no packing launch in between); 0: separate packs
 BN_WRITES_SPLIT = os.environ.get("CLAVA_BN_SPLIT", "1") != "0"
 c_u64 = ctypes.c_ulonglong
@@ -230,7 +231,19 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
     main = torch.cuda.current_stream()
     keep_alive = []
 
+    # `side`: one stream or a list of them.  The weight-gradient products of different layers are independent of each other,
+    # and none of them fills the chip: taken round robin over two streams they overlap with each other as well (on ONE side
+    # stream their sum, 335 us of an 800 us step, was the backward's long pole beside a 290 us input-gradient chain).
+    sides = [] if side is None else (list(side) if isinstance(side, (list, tuple)) else [side])
+    turn = [0]
+
+    def next_side():
+        s_ = sides[turn[0] % len(sides)]
+        turn[0] += 1
+        return s_
+
     def param_grads(prefix, dy, inp):
+        side = next_side() if sides else None
         if side is not None:
             ev = torch.cuda.Event()
             ev.record(main)
@@ -273,6 +286,7 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
             # bias gradient riding along, on the side stream) and by the input-gradient product
             if dzs is None:
                 dzs = ops.split_pack(dz, split.shift_g[i], split.flag, out=split.buf(("g", i), B, lin.out_features, dev))
+            side = next_side() if sides else None
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -297,9 +311,9 @@ def classifier_backward(clf, saved, logits, labels, lse, scale, layout, slabs, k
         d_a1 = ops.linear_dgrad(g, clf.time_embed[2].weight.detach())
         d_z1 = _tr._silu_backward(z1, d_a1)
     param_grads("time_embed.0", d_z1, te)
-    if side is not None:
+    for s_ in sides:
         done = torch.cuda.Event()
-        done.record(side)
+        done.record(s_)
         main.wait_event(done)
     return keep_alive          # tensors the side stream reads: the caller keeps them until the next step
 
@@ -344,6 +358,7 @@ class ClassifierTrainer:
         self._window = []
         self._graph = None
         self._side = None
+        self._sides = None
         self._keep = None
         self.world = 1
         self.dist = None
@@ -441,12 +456,13 @@ class ClassifierTrainer:
         rows, lse, acc1, acc5 = cross_entropy(logits, labels)
         if self._side is None and os.environ.get("CLAVA_TRAIN_STREAMS", "2") != "1":
             self._side = torch.cuda.Stream(device=self.device)
+            self._sides = [self._side] + [torch.cuda.Stream(device=self.device) for _ in range(max(0, CLF_WGRAD_STREAMS - 1))]
         loss = _tr._device_sum(rows, 1.0 / B)          # the backward starts from it (`loss.backward(loss)`, :700)
         # the two accuracies are only reported: summed on the weight-gradient stream, which the backward joins at its end
         a1 = _tr._device_sum(acc1, 1.0 / B, self._side)
         a5 = _tr._device_sum(acc5, 1.0 / B, self._side) if acc5 is not None else None
         self._keep = classifier_backward(clf, saved, logits, labels, lse, loss, self.layout, self.slabs, keeps, self.seed, 0,
-                                         self.step_dev, side=self._side, split=split, collect=collect)
+                                         self.step_dev, side=self._sides if self._side is not None else None, split=split, collect=collect)
         self.step_dev += 1
         return loss, a1, a5, (saved, logits, rows, lse, acc1, acc5, x_t, t)
 
