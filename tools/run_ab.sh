@@ -1,9 +1,8 @@
+# Scratch runner for A/B experiments on the GPU box (gpurun -- 'bash tools/run_ab.sh'): edit freely.  As committed: the full
+# GPU suite, the smoke check and the default bench, each under its own time limit.
 set -e
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/clf_tl
-mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace -d $O -o p --output-format csv -- python3 tools/bench_classifier_train.py > $O.log 2>&1
-T=$(ls $O/*/p_kernel_trace.csv $O/p_kernel_trace.csv 2>/dev/null | head -1)
-python3 tools/trace_timeline.py $T 170 adamw_ema > gpurun_out/clf_timeline.txt
-rm -rf $O
-cat gpurun_out/clf_timeline.txt
+timeout -k 10 1100 python -u -m pytest -x -q --timeout 300 --timeout-method thread tests -m gpu > gpurun_out/t_full.log 2>&1 || { tail -40 gpurun_out/t_full.log; exit 1; }
+tail -3 gpurun_out/t_full.log
+timeout -k 10 120 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
+timeout -k 10 600 python3 bench.py > gpurun_out/bench_last.log 2> gpurun_out/bench_last.err
+tail -c 300 gpurun_out/bench_last.log
