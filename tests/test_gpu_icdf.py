@@ -70,6 +70,16 @@ def test_reverse_step_draws_follow_the_exact_posterior(sampler, t):
         if dof >= 2:
             # (the exact chi-square quantile: its right tail is much heavier than a normal's at a dozen degrees of freedom)
             assert chi < chi2.isf(1e-6, dof), (sampler, t, k, chi, dof)
+    # one t for the whole launch (what a chain passes): the per-feature constants then come from the workgroup's LDS table
+    # instead of being evaluated per block - the same function on the same arguments, so exactly the same draws
+    from clavaddpm_amd._lib import c_int, check, ptr, stream_ptr
+    one_t = torch.empty((B, len(K)), device=DEV, dtype=torch.int32)
+    sched = d._c_schedule()
+    check(lib().clava_multinomial_step_f32(ctypes.byref(sched), c_int(0), c_int(B), c_int(len(K)), c_int(sumK), ptr(d._offsets_i32),
+                                           ptr(d._log_k), ptr(logits), c_int(sumK), ptr(idx), ptr(one_t), None, c_int(sumK), None, c_int(0),
+                                           None, c_int(0), None, c_int(t), ctypes.c_ulonglong(1234 + t), ctypes.c_ulonglong(0),
+                                           ctypes.c_uint(3), stream_ptr()), "clava_multinomial_step_f32")
+    assert np.array_equal(one_t.cpu().numpy(), out)
     # a pure function of (seed, step, global row, feature): the same call repeats, another step index draws afresh
     again, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=3)
     other, _ = d._categorical_step(0, logits, idx, tt, None, False, seed=1234 + t, step_index=4)
