@@ -109,3 +109,24 @@ def test_icdf_draws_do_not_depend_on_how_rows_are_cut(sampler):
     whole = run(0, B, 0)
     assert torch.equal(whole[1000:2200], run(1000, 2200, 1000))
     assert int(whole.min()) >= 0 and all(int(whole[:, f].max()) < k for f, k in enumerate(K))
+
+
+def test_whole_chain_with_wide_categorical_features_is_invariant_to_row_cuts():
+    """An unguided chain on a mixed table with 70- and 300-class features and in-kernel draws (the production path: the
+    inverse-CDF sampler, four wide blocks per Philox call keyed by the global row): rows [a, b) of one call equal a call of
+    those rows alone at row_offset = a, bit for bit; categories in range, reproducible for a seed."""
+    K, n_num, T = [3, 70, 300, 9, 129], 2, 20
+    torch.manual_seed(0)
+    net = MLPDiffusion(n_num + sum(K), 0, "none", {"d_layers": [128, 128], "dropout": 0.0}).to(DEV).eval()
+    d = GaussianMultinomialDiffusion(np.array(K), n_num, net, num_timesteps=T, device=torch.device(DEV)).to(DEV).eval()
+    full, _ = d.sample(300, torch.ones(1), seed=21, noise=None)
+    again, _ = d.sample(300, torch.ones(1), seed=21)
+    assert torch.equal(full, again) and torch.isfinite(full).all()
+    cats = full[:, n_num:]
+    assert torch.equal(cats, cats.round()) and bool((cats >= 0).all()) and all(int(cats[:, f].max()) < K[f] for f in range(len(K)))
+    assert len(set(cats[:, 2].long().tolist())) > 20                    # the 300-class feature does not collapse
+    part_a, _ = d.sample(100, torch.ones(1), seed=21, row_offset=0)
+    part_b, _ = d.sample(200, torch.ones(1), seed=21, row_offset=100)
+    assert torch.equal(torch.cat([part_a, part_b]), full)
+    other, _ = d.sample(300, torch.ones(1), seed=22)
+    assert not torch.equal(other[:, n_num:], cats)
