@@ -174,10 +174,11 @@ inline bool bits_layer(const clava_split_net* net, int l) {
 }
 
 int split_net_forward(const clava_split_net* net, const char* x, int M, const float* rowadd0, char* const* outs, float* last,
-                      int ld_last, int* overflow, hipStream_t st, int l0 = 0, unsigned char* const* bits = nullptr) {
+                      int ld_last, int* overflow, hipStream_t st, int l0 = 0, unsigned char* const* bits = nullptr, int l_end = -1) {
     const char* in = x;                           // l0 > 0: x = activation of layer l0 - 1
     int shift_in = l0 == 0 ? net->shift_in : net->shift_out[l0 - 1];
-    for (int l = l0; l < net->n_layers; ++l) {
+    if (l_end < 0) l_end = net->n_layers;         // layers [l0, l_end)
+    for (int l = l0; l < l_end; ++l) {
         const bool is_last = l == net->n_layers - 1;
         SplitGemmArgs g;
         g.A = in; g.W = (const char*)net->w[l];
@@ -207,10 +208,12 @@ int split_net_forward(const clava_split_net* net, const char* x, int M, const fl
 // denoiser's eps is complete) and *fused is set
 int split_net_input_grad(const clava_split_net* net, int M, char* const* outs, const char* dlast, char* const* grads, float* gx,
                          int ld_gx, float alpha, int* overflow, hipStream_t st, unsigned char* const* bits = nullptr,
-                         const GaussStepArgs* fuse = nullptr, hipEvent_t wait_before_last = nullptr, bool* fused = nullptr) {
+                         const GaussStepArgs* fuse = nullptr, hipEvent_t wait_before_last = nullptr, bool* fused = nullptr,
+                         int l_from = -1) {
     const char* gin = dlast;
-    int shift_g = net->shift_dlast;
-    for (int l = net->n_layers - 1; l >= 0; --l) {
+    if (l_from < 0) l_from = net->n_layers - 1;   // l_from < n_layers - 1: dlast = grads[l_from + 1] of a fused tail
+    int shift_g = (l_from == net->n_layers - 1) ? net->shift_dlast : net->shift_grad[l_from + 1];
+    for (int l = l_from; l >= 0; --l) {
         SplitGemmArgs g;
         g.A = gin; g.W = (const char*)net->wt[l];
         g.M = M; g.N = net->dims[l]; g.Kp = (net->dims[l + 1] + 31) & ~31; g.K = net->dims[l + 1];
@@ -269,7 +272,7 @@ int split_forward_range(const clava_split_net* net, int l0, int l1, const char* 
 }
 
 int split_grad_range(const clava_split_net* net, int l_hi, int l_lo, int M, char* const* outs, const char* gin, char* const* grads,
-                     int* overflow, hipStream_t st) {
+                     int* overflow, hipStream_t st, unsigned char* const* bits = nullptr) {
     for (int l = l_hi; l >= l_lo; --l) {
         SplitGemmArgs g;
         g.A = gin; g.W = (const char*)net->wt[l];
@@ -278,7 +281,9 @@ int split_grad_range(const clava_split_net* net, int l_hi, int l_lo, int M, char
         g.bias = nullptr; g.bias2 = nullptr; g.act = CLAVA_ACT_NONE;
         g.mask = nullptr; g.pitchMask = 0; g.mask_slope = 0.f;
         if (net->act[l - 1] != CLAVA_ACT_NONE) {
-            g.mask = outs[l - 1]; g.pitchMask = split_pitch(net->dims[l]); g.mask_slope = act_slope(net->act[l - 1]);
+            g.mask_slope = act_slope(net->act[l - 1]);
+            if (bits && bits[l - 1]) { g.mask_bits = bits[l - 1]; g.pitchBits = bits_pitch(net->dims[l]); }
+            else { g.mask = outs[l - 1]; g.pitchMask = split_pitch(net->dims[l]); }
         }
         g.scale_acc = ldexpf(1.f, -((l == net->n_layers - 1 ? net->shift_dlast : net->shift_grad[l + 1]) + net->shift_w[l]));
         g.alpha = 1.f;
@@ -663,8 +668,16 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
     // (cat_input.hip) and the [B, sum K] log-one-hot image is never written; CLAVA_CAT_GATHER=0 keeps the dense product
     const bool cat_gather = c->m > 0 && !k && d->cat_wt && d->cat_bias && (c->n_num == 0 || d->num_wt) && d->dims[1] % 128 == 0 &&
                             nd >= 2 && env_int("CLAVA_CAT_GATHER", 1) != 0;
-    const bool den_fused = !cat_gather && c->n_num > 0 && denoiser_fusable(c, d);
-    const bool cls_fused = classifier_fusable(c, k);
+    // fused narrow-stack kernels, part by part (CLAVA_FUSED_PARTS: 1 classifier front + back, 2 classifier tail, 8 denoiser
+    // front, 16 denoiser head + Gaussian step; the front's kernel does not store the two activations the per-layer
+    // input-gradient products would read, so front and back go together).  Default: the classifier's three - the guidance
+    // stream is the step's critical path and they take 8 launches off it; the denoiser's two measure slower than the
+    // launches they replace.
+    const int parts = env_int("CLAVA_FUSED_PARTS", 7);
+    const bool den_fusable = !cat_gather && c->n_num > 0 && denoiser_fusable(c, d);
+    const bool den_front = den_fusable && (parts & 8), den_head = den_fusable && (parts & 16);
+    const bool cls_fusable = classifier_fusable(c, k);
+    const bool cls_ends = cls_fusable && (parts & 1), cls_tail = cls_fusable && (parts & 2);
     if (n_groups > 1) CLAVA_CHECK_HIP(hipEventRecord(pool->begin, caller), "sample_chain_f16x3: fork");
     typedef ChainGroup Group;
     for (int g = 0; g < n_groups; ++g) {
@@ -709,10 +722,11 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             // Gaussian step inside the guidance's last launch (narrow_split_gauss): the guidance stream, the step's critical
             // path, then runs from step to step without a hand-over; the denoiser stream waits for it once per step
             // (eligibility of the guidance's last product for the narrow kernel, narrow.hip: <= 16 outputs, W within 64 KB of LDS)
-            const bool fuse_gauss = k && G.cls != G.den && c->n_num > 0 && c->m == 0 && !den_fused && !cls_fused && !cat_gather &&
-                                    k->dims[0] == c->n_num && c->n_num <= 16 &&
-                                    (long long)c->n_num * ((k->dims[1] + 31) & ~31) <= 16384 && env_int("CLAVA_NARROW_SPLIT", 1) != 0 &&
-                                    env_int("CLAVA_FUSE_GAUSS", 1) != 0;
+            // (or inside the fused back kernel, which ends in the same product)
+            const bool fuse_gauss = k && G.cls != G.den && c->n_num > 0 && c->m == 0 && !den_head && !cat_gather &&
+                                    k->dims[0] == c->n_num && env_int("CLAVA_FUSE_GAUSS", 1) != 0 &&
+                                    (cls_ends || (c->n_num <= 16 && (long long)c->n_num * ((k->dims[1] + 31) & ~31) <= 16384 &&
+                                                  env_int("CLAVA_NARROW_SPLIT", 1) != 0));
             if (G.cls != G.den && (s == 0 || !fuse_gauss)) {
                 CLAVA_CHECK_HIP(hipEventRecord(pool->fork[gi], G.den), "sample_chain_f16x3: step fork");
                 CLAVA_CHECK_HIP(hipStreamWaitEvent(G.cls, pool->fork[gi], 0), "sample_chain_f16x3: step fork");
@@ -722,8 +736,8 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             char* outs[64];
             for (int l = 0; l < nd - 1; ++l) outs[l] = rowp(w.den[l & 1], split_pitch(hw), r0);
             outs[nd - 1] = nullptr;
-            if (den_fused) {
-                // proj + first hidden block in one kernel; the head runs fused with the Gaussian step below
+            if (den_front) {
+                // proj + first hidden block in one kernel; the head may run fused with the Gaussian step below
                 FusedFrontArgs fa;
                 fa.B = R; fa.x = x_split; fa.pitch_x = split_pitch(D);
                 fa.stream = (const char*)d->fs_front;
@@ -734,7 +748,8 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 fa.overflow = overflow;
                 rc = clava_launch_den_front(fa, D, G.den);
                 if (rc) return rc;
-                rc = split_forward_range(d, 2, nd - 2, outs[1], R, outs, overflow, G.den);
+                rc = den_head ? split_forward_range(d, 2, nd - 2, outs[1], R, outs, overflow, G.den)
+                              : split_net_forward(d, outs[1], R, nullptr, outs, model_out, ldm, overflow, G.den, 2);
                 if (rc) return rc;
             } else if (cat_gather) {
                 CatInputArgs ca = {};
@@ -752,8 +767,9 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 if (rc) return rc;
                 rc = split_net_forward(d, outs[0], R, nullptr, outs, model_out, ldm, overflow, G.den, 1);
                 if (rc) return rc;
-            } else {
-                rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, ldm, overflow, G.den);
+            } else {                               // (all layers but the head when the head runs fused with the step)
+                rc = split_net_forward(d, x_split, R, c->denoiser_emb + (size_t)t * emb_w, outs, model_out, ldm, overflow, G.den, 0,
+                                       nullptr, den_head ? nd - 1 : -1);
                 if (rc) return rc;
             }
             // ---- the fused Gaussian step's arguments (it writes float(x_next) straight into the next denoiser input)
@@ -780,7 +796,6 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             if (fuse_gauss)                        // the denoiser's eps is complete behind this event
                 CLAVA_CHECK_HIP(hipEventRecord(pool->fork[gi], G.den), "sample_chain_f16x3: denoiser done");
             // ---- guidance: grad_x log p(y | x_t), on the group's second stream
-            const float* grad = nullptr;
             if (k) {
                 const int nk = k->n_layers, C = k->dims[nk];
                 const hipStream_t st = G.cls;
@@ -794,10 +809,17 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                 char* grads[64];
                 for (int l = 1; l < nk; ++l) grads[l] = rowp(w.cls_grad[l & 1], split_pitch(gw), r0);
                 grads[0] = nullptr;
-                if (cls_fused) {
-                    // front (3 layers) -> 4 wide products -> tail (2 layers, log-softmax gradient, 2 input-gradient products)
-                    // -> 4 wide input-gradient products -> back (3 input-gradient products): 11 launches instead of 19
-                    const float* emb = c->classifier_emb + (size_t)t * k->dims[1];
+                // front (3 layers) -> 4 wide products -> tail (2 layers, log-softmax gradient, 2 input-gradient products)
+                // -> 4 wide input-gradient products -> back (3 input-gradient products): 11 launches instead of 19 with
+                // every part fused
+                const float* emb = c->classifier_emb + (size_t)t * k->dims[1];
+                unsigned char* cls_bits[64] = {};
+                for (int l = 0; l + 1 < nk; ++l)
+                    cls_bits[l] = w.cls_bits[l] ? w.cls_bits[l] + (size_t)r0 * bits_pitch(k->dims[l + 1]) : nullptr;
+                if (cls_ends) cls_bits[2] = nullptr;   // the fused front stores planes only
+                // ---- forward up to the tail (or to the logits)
+                const int fwd_end = cls_tail ? 7 : nk;
+                if (cls_ends) {
                     FusedFrontArgs fa;
                     fa.B = R; fa.x = x_split; fa.pitch_x = split_pitch(D);
                     fa.stream = (const char*)k->fs_front;
@@ -807,8 +829,15 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     fa.overflow = overflow;
                     rc = clava_launch_cls_front(fa, c->n_num, st);
                     if (rc) return rc;
-                    rc = split_forward_range(k, 3, 6, cls_out[2], R, cls_out, overflow, st);
-                    if (rc) return rc;
+                    rc = split_net_forward(k, cls_out[2], R, nullptr, cls_out, logits, C, overflow, st, 3, cls_bits, fwd_end);
+                } else {
+                    rc = split_net_forward(k, x_split, R, emb, cls_out, logits, C, overflow, st, 0, cls_bits, fwd_end);
+                }
+                if (rc) return rc;
+                // ---- the stack's end and the first input-gradient products
+                const char* gin = dlogits;
+                int g_from = nk - 1;
+                if (cls_tail) {
                     FusedTailArgs ta;
                     ta.B = R; ta.C = C;
                     ta.a6 = cls_out[6]; ta.pitch_a6 = split_pitch(256);
@@ -824,7 +853,17 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     ta.overflow = overflow;
                     rc = clava_launch_cls_tail(ta, st);
                     if (rc) return rc;
-                    rc = split_grad_range(k, 6, 3, R, cls_out, grads[7], grads, overflow, st);
+                    gin = grads[7];
+                    g_from = 6;
+                } else {
+                    ProfScope prof(PROF_SELECT_GRAD, 0.0, 8.0 * R * C, st);
+                    hipLaunchKernelGGL(logsoftmax_select_grad_split_kernel, dim3((R + 3) / 4), dim3(256), 0, st, logits, C, c->y + r0,
+                                       dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), R, C);
+                    CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
+                }
+                // ---- the remaining input-gradient products
+                if (cls_ends) {
+                    rc = split_grad_range(k, g_from, 3, R, cls_out, gin, grads, overflow, st, cls_bits);
                     if (rc) return rc;
                     FusedBackArgs ba;
                     ba.B = R; ba.n_num = c->n_num;
@@ -839,26 +878,17 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     ba.scale_acc_g0 = c->guidance_scale * ldexpf(1.f, -(k->shift_grad[1] + k->shift_w[0]));
                     ba.gx = gx; ba.ld_gx = c->n_num;
                     ba.overflow = overflow;
-                    rc = clava_launch_cls_back(ba, st);
-                    if (rc) return rc;
-                } else {
-                    unsigned char* cls_bits[64] = {};
-                    for (int l = 0; l + 1 < nk; ++l)
-                        cls_bits[l] = w.cls_bits[l] ? w.cls_bits[l] + (size_t)r0 * bits_pitch(k->dims[l + 1]) : nullptr;
-                    rc = split_net_forward(k, x_split, R, c->classifier_emb + (size_t)t * k->dims[1], cls_out, logits, C, overflow, st, 0,
-                                           cls_bits);
-                    if (rc) return rc;
-                    {
-                        ProfScope prof(PROF_SELECT_GRAD, 0.0, 8.0 * R * C, st);
-                        hipLaunchKernelGGL(logsoftmax_select_grad_split_kernel, dim3((R + 3) / 4), dim3(256), 0, st, logits, C, c->y + r0,
-                                           dlogits, split_pitch(C), ldexpf(1.f, k->shift_dlast), R, C);
-                        CLAVA_CHECK_LAUNCH("clava_logsoftmax_select_grad_split");
+                    if (fuse_gauss) {              // the denoiser's eps is complete behind fork[gi]
+                        CLAVA_CHECK_HIP(hipStreamWaitEvent(st, pool->fork[gi], 0), "guidance: wait for the denoiser");
+                        ba.gauss = 1; ba.g = gs;
+                        gauss_done = true;
                     }
-                    rc = split_net_input_grad(k, R, cls_out, dlogits, grads, gx, c->n_num, c->guidance_scale, overflow, st, cls_bits,
-                                              fuse_gauss ? &gs : nullptr, fuse_gauss ? pool->fork[gi] : nullptr, &gauss_done);
-                    if (rc) return rc;
+                    rc = clava_launch_cls_back(ba, st);
+                } else {
+                    rc = split_net_input_grad(k, R, cls_out, gin, grads, gx, c->n_num, c->guidance_scale, overflow, st, cls_bits,
+                                              fuse_gauss ? &gs : nullptr, fuse_gauss ? pool->fork[gi] : nullptr, &gauss_done, g_from);
                 }
-                grad = gx;
+                if (rc) return rc;
                 if (G.cls != G.den) {
                     CLAVA_CHECK_HIP(hipEventRecord(pool->join[gi], G.cls), "sample_chain_f16x3: step join");
                     CLAVA_CHECK_HIP(hipStreamWaitEvent(G.den, pool->join[gi], 0), "sample_chain_f16x3: step join");
@@ -871,7 +901,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
             }
             if (c->n_num > 0 && !gauss_done) {
                 const GaussStepArgs& g = gs;
-                if (den_fused) {               // the head's eps goes from the accumulators straight into the step
+                if (den_head) {                // the head's eps goes from the accumulators straight into the step
                     FusedHeadArgs ha;
                     ha.stream = (const char*)d->fs_head;
                     ha.h = outs[nd - 2]; ha.pitch_h = split_pitch(d->dims[nd - 1]);

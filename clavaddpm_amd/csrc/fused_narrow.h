@@ -50,6 +50,8 @@ struct FusedBackArgs {
     float scale_acc_g0 = 1.f;                           // includes classifier_scale
     float* gx = nullptr; int ld_gx = 0;
     int* overflow = nullptr;
+    int gauss = 0;                                      // 1: the row's Gaussian reverse step follows in the same thread
+    GaussStepArgs g;                                    // (g.grad = gx, g.eps = the denoiser's output, complete before the launch)
 };
 
 struct FusedHeadArgs {

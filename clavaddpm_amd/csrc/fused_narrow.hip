@@ -415,7 +415,9 @@ __global__ void __launch_bounds__(256) cls_tail_kernel(FusedTailArgs a) {
 // ---------------------------------------------------------------------------------------------------- classifier back
 // g3 [B,256] (d/d pre-activation of L2) -> x W2 -> mask of L1 (recomputed from x: two small products) -> x W1 -> x W0 ->
 // gx [B, n_num] = classifier_scale * d/dx, float32.  Stream: L0 (4 KS0 pairs), L1 (32), L2^T (64), L1^T (32), L0^T (8).
-template <int KS0>
+// GAUSS: gx is the guidance gradient of a reverse step whose Gaussian posterior step (step.h: gauss_step_element) follows in
+// the same thread, as in narrow_split_kernel<.., true>: one launch and one cross-stream hand-over less per step.
+template <int KS0, bool GAUSS>
 __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
     const Lane L = lane_of(a.B);
     const WRing r = make_ring(a.stream, a.n_chunks);
@@ -455,7 +457,11 @@ __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int c = feat(0, v, L.h);
-                if (c < a.n_num) a.gx[L.row * a.ld_gx + c] = acc[0][v] * a.scale_acc_g0;      // alpha folded into the scale
+                if (c < a.n_num) {
+                    a.gx[L.row * a.ld_gx + c] = acc[0][v] * a.scale_acc_g0;                   // alpha folded into the scale
+                    if constexpr (GAUSS)         // (reads the gradient this thread just stored)
+                        gauss_step_element(a.g, (int)L.row, c, a.g.eps[(size_t)L.row * a.g.ld_eps + c]);
+                }
             }
         }
     }
@@ -563,8 +569,16 @@ int clava_launch_cls_back(FusedBackArgs a, hipStream_t st) {
     const int ks0 = a.n_num <= 16 ? 1 : 2;
     a.n_chunks = chunks_of(4 * ks0 + 136);
     const double fl = 2.0 * a.B * (256.0 * 128 + 2 * 128.0 * 128 + 2 * 128.0 * a.n_num), by = (double)a.B * (1024 + 128 + 4.0 * a.n_num);
-    return ks0 == 1 ? launch_rows(cls_back_kernel<1>, 9, a, a.B, st, "cls_back", fl, by)
-                    : launch_rows(cls_back_kernel<2>, 10, a, a.B, st, "cls_back", fl, by);
+    if (a.gauss) {
+        if (!a.g.eps || a.g.grad != a.gx || a.g.ld_grad != a.ld_gx || a.g.B != a.B || a.g.n_num != a.n_num) {
+            clava_set_error("cls_back: the fused Gaussian step must take this launch's gradient and the denoiser's eps");
+            return CLAVA_ERR_ARG;
+        }
+        return ks0 == 1 ? launch_rows(cls_back_kernel<1, true>, 14, a, a.B, st, "cls_back_gauss", fl, by)
+                        : launch_rows(cls_back_kernel<2, true>, 15, a, a.B, st, "cls_back_gauss", fl, by);
+    }
+    return ks0 == 1 ? launch_rows(cls_back_kernel<1, false>, 9, a, a.B, st, "cls_back", fl, by)
+                    : launch_rows(cls_back_kernel<2, false>, 10, a, a.B, st, "cls_back", fl, by);
 }
 
 bool clava_den_head_supports(int hidden) { return hidden == 256 || hidden == 512 || hidden == 1024; }

@@ -241,7 +241,7 @@ class SplitNet:
         d = self.dims
         pk = lambda l, **kw: pack_fused(fw[l], self.shift_w[l], **kw)
         pkt = lambda l, **kw: pack_fused(fw[l].t().contiguous(), self.shift_w[l], **kw)
-        narrow_in = d[0] <= 32 and d[1] == 128 and os.environ.get("CLAVA_FUSED", "0") != "0"
+        narrow_in = d[0] <= 32 and d[1] == 128 and os.environ.get("CLAVA_FUSED", "1") != "0"
         if narrow_in and not need_grad and n >= 3 and d[2] in (256, 512, 1024) and d[n - 1] in (256, 512, 1024) and d[n] <= 32:
             self.fs_front = fused_stream([pk(0), pk(1)])                         # proj, first hidden block
             self.fs_head = fused_stream([pk(n - 1)])
@@ -328,7 +328,7 @@ def prepare(ws, bs, acts, sc, sh, emb_table, x_cal, shift_in, y_cal=None, need_g
     tensor by the allocator while the entry exists."""
     watch = [t.detach() for t in (watch if watch is not None else list(ws) + list(bs)) if t is not None]
     key = tuple((t.data_ptr(), tuple(t.shape)) for t in watch) + (emb_table.shape[0], shift_in, need_grad, x_cal.shape[1],
-                                                                   os.environ.get("CLAVA_FUSED", "0"), cat)
+                                                                   os.environ.get("CLAVA_FUSED", "1"), cat)
     hit = _cache.get(key)
     vers = _versions(watch)
     if hit is not None:

@@ -359,11 +359,26 @@ def test_fused_narrow_stack_kernels_match_the_per_layer_products(n_num, C, monke
     split_nets.set_gemm_mode("f16x3")
     n0 = split_nets.fallback_count
     out = {}
+    monkeypatch.setenv("CLAVA_FUSED_PARTS", "31")                # every fused kernel (the default leaves the denoiser's two out)
     for fused in ("1", "0"):
         monkeypatch.setenv("CLAVA_FUSED", fused)
         out[fused], _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, noise=nz, n_steps=steps)
     assert split_nets.fallback_count == n0
     assert relerr(out["1"], out["0"]) < 2e-6
+    # the parts one by one and as shipped (classifier front + back with the Gaussian step inside, classifier tail), and the
+    # shipped set with the Gaussian step as its own launch: the same arithmetic, so the same bits as the set above where the
+    # same kernels run
+    monkeypatch.setenv("CLAVA_FUSED", "1")
+    for parts in ("1", "2", "7", "8", "16"):
+        monkeypatch.setenv("CLAVA_FUSED_PARTS", parts)
+        o, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, noise=nz, n_steps=steps)
+        assert relerr(o, out["0"]) < 2e-6, parts
+        if parts == "7":
+            monkeypatch.setenv("CLAVA_FUSE_GAUSS", "0")
+            o2, _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, noise=nz, n_steps=steps)
+            monkeypatch.delenv("CLAVA_FUSE_GAUSS")
+            assert torch.equal(o, o2)
+    monkeypatch.setenv("CLAVA_FUSED_PARTS", "31")
     tb = schedule.tables("cosine", T)
     sub_rows = slice(0, 200)
     nzs = {"z0": nz["z0"][sub_rows], "noise": nz["noise"][:, sub_rows]}
