@@ -827,6 +827,7 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     fa.nt_out = 8;
                     fa.out = cls_out[2]; fa.pitch_out = split_pitch(256);
                     fa.overflow = overflow;
+                    fa.mask1 = reinterpret_cast<unsigned*>(cls_out[1]);       // 16 bytes a row in the unused rows of layer 1's activation
                     rc = clava_launch_cls_front(fa, c->n_num, st);
                     if (rc) return rc;
                     rc = split_net_forward(k, cls_out[2], R, nullptr, cls_out, logits, C, overflow, st, 3, cls_bits, fwd_end);
@@ -867,9 +868,8 @@ static int enqueue_split_chain(const clava_chain* c, const clava_split_net* d, c
                     if (rc) return rc;
                     FusedBackArgs ba;
                     ba.B = R; ba.n_num = c->n_num;
-                    ba.x = x_split; ba.pitch_x = split_pitch(D);
                     ba.g3 = grads[3]; ba.pitch_g3 = split_pitch(256);
-                    ba.l[0] = fused_layer(k, 0, emb); ba.l[1] = fused_layer(k, 1, nullptr);
+                    ba.mask1 = reinterpret_cast<const unsigned*>(cls_out[1]);
                     ba.stream = (const char*)k->fs_back;
                     ba.scale_acc_g2 = ldexpf(1.f, -(k->shift_grad[3] + k->shift_w[2]));
                     ba.scale_out_g2 = ldexpf(1.f, k->shift_grad[2]); ba.slope1 = act_slope(k->act[1]);

@@ -24,6 +24,8 @@ struct FusedFrontArgs {
     int nt_out = 0;
     char* out = nullptr; long long pitch_out = 0;
     int* overflow = nullptr;
+    unsigned* mask1 = nullptr;                          // cls_front: [B][2 lane halves][2] words, act'(l[1]) > 0 as bits in the
+                                                        // lanes' register order - read back by cls_back (private layout)
 };
 
 struct FusedTailArgs {
@@ -42,9 +44,8 @@ struct FusedTailArgs {
 struct FusedBackArgs {
     int B = 0, n_num = 0;
     const char* stream = nullptr; int n_chunks = 0;
-    const char* x = nullptr; long long pitch_x = 0;
     const char* g3 = nullptr; long long pitch_g3 = 0;   // d/d(pre-activation of l[2]) [B, 256] split rows
-    FusedLayer l[2];                                    // proj (+ emb row) and 128 -> 128, recomputed for the mask of l[1]
+    const unsigned* mask1 = nullptr;                    // act'(l[1]) bits as cls_front stored them
     float scale_acc_g2 = 1.f, scale_out_g2 = 1.f, slope1 = 0.f;
     float scale_acc_g1 = 1.f, scale_out_g1 = 1.f;
     float scale_acc_g0 = 1.f;                           // includes classifier_scale

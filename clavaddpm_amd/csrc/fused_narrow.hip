@@ -74,6 +74,53 @@ __device__ __forceinline__ void load_act(const char* __restrict__ rowp, int h, h
     }
 }
 
+// The same fragments for a WIDE activation (NB 128-byte blocks = 2 NB steps), fetched row-contiguously: one load
+// instruction covers 8 rows x 128 bytes (8 cache lines; the per-lane fetch above touches 32 lines per instruction for 512
+// bytes, and with four wavefronts on one texture unit that was ~9 us of a 40 us kernel), then the wavefront transposes block
+// by block through a private 32 x 136-byte LDS tile (LDS executes a wavefront's accesses in order: no waits between a
+// block's reads and the next block's writes; the 136-byte row stride keeps the 8-byte reads conflict-free).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int STAGE_ROW = 136, STAGE_WAVE = 32 * STAGE_ROW;
+
+template <int NB>
+struct StagedAct {
+    u32x4 raw[NB][4];
+    // issue the loads (rows of the wavefront's tile beyond B - 1 read row B - 1)
+    __device__ __forceinline__ void issue(const char* __restrict__ base, long long pitch, long long row0, int B) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long row = row0 + 8 * i + (lane >> 3);
+            row = row < B ? row : (long long)B - 1;
+            const char* p = base + row * pitch + (lane & 7) * 16;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) raw[b][i] = *reinterpret_cast<const u32x4*>(p + b * 128);
+        }
+    }
+    // transpose into the fragment registers of lane (m, h); `tile` = this wavefront's STAGE_WAVE bytes of LDS
+    __device__ __forceinline__ void finish(char* tile, h8 (&ah)[2 * NB], h8 (&al)[2 * NB]) {
+        const int lane = threadIdx.x & 63;
+        char* wr = tile + (lane >> 3) * STAGE_ROW + (lane & 7) * 16;
+        const char* rd = tile + (lane & 31) * STAGE_ROW + (lane >> 5) * 8;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<u32x2*>(wr + 8 * i * STAGE_ROW) = u32x2{raw[b][i][0], raw[b][i][1]};
+                *reinterpret_cast<u32x2*>(wr + 8 * i * STAGE_ROW + 8) = u32x2{raw[b][i][2], raw[b][i][3]};
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const h4 a0 = *reinterpret_cast<const h4*>(rd + 32 * s2), a1 = *reinterpret_cast<const h4*>(rd + 32 * s2 + 16);
+                const h4 b0 = *reinterpret_cast<const h4*>(rd + 64 + 32 * s2), b1 = *reinterpret_cast<const h4*>(rd + 64 + 32 * s2 + 16);
+                ah[2 * b + s2] = h8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                al[2 * b + s2] = h8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+        }
+    }
+};
+
 // ---- the weight stream: three 32 KB LDS buffers filled by LDS-DMA, 16 fragment pairs (hi 1 KB | lo 1 KB) per chunk
 constexpr int RING_CHUNK = 32768, RING_BUFS = 3, PAIRS_PER_CHUNK = 16, WAVES = WAVES_PER_WG, DMA_PER_WAVE = RING_CHUNK / 1024 / WAVES;
 
@@ -158,8 +205,11 @@ __device__ __forceinline__ int feat(int nt, int v, int h) { return 32 * nt + 8 *
 // Epilogue of a forward layer: y = act(acc * scale_acc + bias) in place (true values).  `bias` points into the LDS copy
 // made by stage_bias (32 * n-tiles floats, padded; the broadcast time-embedding row already added for layer 0): a global
 // load here would expose an L2 / HBM round trip once per layer.
+// The activation is max(x, slope * x) (slope 0 / 0.01 / 1 for ReLU / LeakyReLU / none): straight-line code - with the
+// activation tested per element the compiler emitted a scalar branch for each of a lane's 64 values.
 template <int NT>
 __device__ __forceinline__ void epi_forward(f32x16 (&acc)[NT], int nt0, int h, const float* bias, float scale_acc, int act) {
+    const float slope = act == CLAVA_ACT_RELU ? 0.f : (act == CLAVA_ACT_LEAKY ? 0.01f : 1.f);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -168,10 +218,8 @@ __device__ __forceinline__ void epi_forward(f32x16 (&acc)[NT], int nt0, int h, c
             const f32x4 b = *reinterpret_cast<const f32x4*>(bias + f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = acc[nt][4 * g + r] * scale_acc + b[r];
-                if (act == CLAVA_ACT_RELU) x = x > 0.f ? x : 0.f;
-                else if (act == CLAVA_ACT_LEAKY) x = x > 0.f ? x : 0.01f * x;
-                acc[nt][4 * g + r] = x;
+                const float x = acc[nt][4 * g + r] * scale_acc + b[r];
+                acc[nt][4 * g + r] = fmaxf(x, slope * x);
             }
         }
 }
@@ -237,6 +285,25 @@ __device__ __forceinline__ void epi_backward(f32x16 (&acc)[NT], const h8 (&mask)
             acc[nt][v] = x * (((float)mask[M0 + 2 * nt + (v >> 3)][v & 7] > 0.f) ? 1.f : slope);
         }
 }
+// the same with the derivative as bits: bit 16 nt + v of the lane's words (mask_bits_of below)
+template <int NT>
+__device__ __forceinline__ void epi_backward_bits(f32x16 (&acc)[NT], const unsigned (&bits)[(NT + 1) / 2], float slope, float scale) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            acc[nt][v] = acc[nt][v] * scale * (((bits[nt >> 1] >> (16 * (nt & 1) + v)) & 1u) ? 1.f : slope);
+}
+// bit 8 s + j of the result = (fragment element j of step s > 0): the lane's 16 NT features in accumulator order
+template <int NT>
+__device__ __forceinline__ void mask_bits_of(const h8 (&ah)[2 * NT], unsigned (&bits)[(NT + 1) / 2]) {
+#pragma unroll
+    for (int w = 0; w < (NT + 1) / 2; ++w) bits[w] = 0u;
+#pragma unroll
+    for (int s = 0; s < 2 * NT; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bits[s >> 2] |= (ah[s][j] > (_Float16)0 ? 1u : 0u) << (8 * (s & 3) + j);
+}
 template <int NT>
 __device__ __forceinline__ void epi_scale(f32x16 (&acc)[NT], float scale) {
 #pragma unroll
@@ -247,8 +314,11 @@ __device__ __forceinline__ void epi_scale(f32x16 (&acc)[NT], float scale) {
 
 // ---------------------------------------------------------------------------------------------------- forward stacks
 constexpr int RING_LDS = RING_CHUNK * RING_BUFS, BIAS_LDS_FLOATS = 2048;
-extern __shared__ __attribute__((aligned(1024))) char ring_mem[];      // the ring, then BIAS_LDS_FLOATS floats of staged biases
+// the ring, then BIAS_LDS_FLOATS floats of staged biases, then one transposition tile per wavefront
+extern __shared__ __attribute__((aligned(1024))) char ring_mem[];
 __device__ __forceinline__ float* bias_lds() { return reinterpret_cast<float*>(ring_mem + RING_LDS); }
+__device__ __forceinline__ char* stage_tile() { return ring_mem + RING_LDS + BIAS_LDS_FLOATS * 4 + (threadIdx.x >> 6) * STAGE_WAVE; }
+__device__ __forceinline__ long long wave_row0() { return ((long long)blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6)) * 32; }
 
 __device__ __forceinline__ WRing make_ring(const char* stream, int n_chunks) {
     WRing r;
@@ -287,6 +357,11 @@ __global__ void __launch_bounds__(256) cls_front_kernel(FusedFrontArgs a) {
         wave_linear<8, 4, P1>(r, a0h, a0l, acc);
         epi_forward<4>(acc, 0, L.h, b1, a.l[1].scale_acc, a.l[1].act);
         to_frags<4>(acc, a.l[1].scale_out, a1h, a1l, ovf);
+        if (a.mask1 && L.valid) {            // what cls_back multiplies its second product by: no recomputation there
+            unsigned bits[2];
+            mask_bits_of<4>(a1h, bits);
+            *reinterpret_cast<u32x2*>(a.mask1 + (L.row * 2 + L.h) * 2) = u32x2{bits[0], bits[1]};
+        }
     }
     {                                        // 256 output columns in two halves: 64 accumulator registers at a time
         f32x16 acc[4];
@@ -335,14 +410,16 @@ __global__ void __launch_bounds__(256) den_front_kernel(FusedFrontArgs a) {
 __global__ void __launch_bounds__(256) cls_tail_kernel(FusedTailArgs a) {
     STAMP(0);
     const Lane L = lane_of(a.B);
+    h8 a6h[16], a7h[8], a7l[8];
+    StagedAct<8> in;
+    in.issue(a.a6, a.pitch_a6, wave_row0(), a.B);            // the oldest loads in flight: what the first product waits for
     const WRing r = make_ring(a.stream, a.n_chunks);
     float ovf = 0.f;      // largest plane magnitude written: beyond the float16 range raises the caller's overflow flag
     float* const b7 = bias_lds(); float* const b8 = b7 + 128;
     stage_bias(b7, a.l7.bias, nullptr, 128); stage_bias(b8, a.l8.bias, nullptr, 64);
-    h8 a6h[16], a7h[8], a7l[8];
     {
         h8 a6l[16];
-        load_act<16>(a.a6 + L.row_ld * a.pitch_a6, L.h, a6h, a6l);
+        in.finish(stage_tile(), a6h, a6l);
         f32x16 acc[4];
         STAMP(1);
         wave_linear<16, 4, 0>(r, a6h, a6l, acc);
@@ -366,21 +443,23 @@ __global__ void __launch_bounds__(256) cls_tail_kernel(FusedTailArgs a) {
                 mx = fmaxf(mx, lg[nt][v]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // softmax = e / sum(e), e = 2^((logit - max) log2 e) on the hardware exp2 (one pass; the padded classes' -inf gives 0):
+        // the rounding of the exponent moves a probability by < 4e-8 absolute
         float sm = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) sm += expf(lg[nt][v] - mx);
+            for (int v = 0; v < 16; ++v) {
+                lg[nt][v] = __builtin_amdgcn_exp2f((lg[nt][v] - mx) * 1.44269504088896340736f);
+                sm += lg[nt][v];
+            }
         sm += __shfl_xor(sm, 32, 64);
-        const float lse = mx + logf(sm);
+        const float inv = 1.f / sm;
         const int yy = a.y[L.row_ld];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int c = feat(nt, v, L.h);
-                lg[nt][v] = (c < a.C) ? ((c == yy ? 1.f : 0.f) - expf(lg[nt][v] - lse)) : 0.f;
-            }
+            for (int v = 0; v < 16; ++v) lg[nt][v] = (feat(nt, v, L.h) == yy ? 1.f : 0.f) - lg[nt][v] * inv;
         to_frags<2>(lg, a.scale_dlast, dlh, dll, ovf);
     }
     STAMP(4);
@@ -413,34 +492,27 @@ __global__ void __launch_bounds__(256) cls_tail_kernel(FusedTailArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------- classifier back
-// g3 [B,256] (d/d pre-activation of L2) -> x W2 -> mask of L1 (recomputed from x: two small products) -> x W1 -> x W0 ->
-// gx [B, n_num] = classifier_scale * d/dx, float32.  Stream: L0 (4 KS0 pairs), L1 (32), L2^T (64), L1^T (32), L0^T (8).
+// g3 [B,256] (d/d pre-activation of L2) -> x W2 -> times act'(L1) (the bits cls_front stored) -> x W1 -> x W0 ->
+// gx [B, n_num] = classifier_scale * d/dx, float32.  Stream: L2^T (64 pairs), L1^T (32), L0^T (8).
 // GAUSS: gx is the guidance gradient of a reverse step whose Gaussian posterior step (step.h: gauss_step_element) follows in
 // the same thread, as in narrow_split_kernel<.., true>: one launch and one cross-stream hand-over less per step.
-template <int KS0, bool GAUSS>
+template <bool GAUSS>
 __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
     const Lane L = lane_of(a.B);
+    StagedAct<8> in;
+    in.issue(a.g3, a.pitch_g3, wave_row0(), a.B);
+    const u32x2 mb = *reinterpret_cast<const u32x2*>(a.mask1 + (L.row_ld * 2 + L.h) * 2);
     const WRing r = make_ring(a.stream, a.n_chunks);
     float ovf = 0.f;      // largest plane magnitude written: beyond the float16 range raises the caller's overflow flag
-    constexpr int P1 = 4 * KS0, P2 = P1 + 32, P3 = P2 + 64, P4 = P3 + 32;
-    float* const b0 = bias_lds(); float* const b1 = b0 + 128;
-    stage_bias(b0, a.l[0].bias, a.l[0].bias2, 128); stage_bias(b1, a.l[1].bias, nullptr, 128);
-    h8 a1h[8];
-    {
-        h8 a0h[8], a0l[8], a1l[8];
-        front_l0<KS0>(r, a.l[0], b0, a.x, a.pitch_x, L, a0h, a0l, ovf);
-        f32x16 acc[4];
-        wave_linear<8, 4, P1>(r, a0h, a0l, acc);
-        epi_forward<4>(acc, 0, L.h, b1, a.l[1].scale_acc, a.l[1].act);
-        to_frags<4>(acc, a.l[1].scale_out, a1h, a1l, ovf);
-    }
+    constexpr int P3 = 64, P4 = P3 + 32;
     h8 g2h[8], g2l[8];
     {
         h8 g3h[16], g3l[16];
-        load_act<16>(a.g3 + L.row_ld * a.pitch_g3, L.h, g3h, g3l);
+        in.finish(stage_tile(), g3h, g3l);
         f32x16 acc[4];
-        wave_linear<16, 4, P2>(r, g3h, g3l, acc);
-        epi_backward<4, 0>(acc, a1h, a.slope1, a.scale_acc_g2);
+        wave_linear<16, 4, 0>(r, g3h, g3l, acc);
+        const unsigned bits[2] = {mb[0], mb[1]};
+        epi_backward_bits<4>(acc, bits, a.slope1, a.scale_acc_g2);
         to_frags<4>(acc, a.scale_out_g2, g2h, g2l, ovf);
     }
     h8 g1h[8], g1l[8];
@@ -504,7 +576,7 @@ __global__ void __launch_bounds__(256) den_head_gauss_kernel(FusedHeadArgs a) {
     }
 }
 
-constexpr int FUSED_LDS = RING_LDS + BIAS_LDS_FLOATS * 4;
+constexpr int FUSED_LDS = RING_LDS + BIAS_LDS_FLOATS * 4 + WAVES_PER_WG * STAGE_WAVE;
 bool g_ring_attr[64][16] = {};
 
 template <typename K, typename A>
@@ -566,19 +638,20 @@ int clava_launch_cls_tail(FusedTailArgs a, hipStream_t st) {
 }
 
 int clava_launch_cls_back(FusedBackArgs a, hipStream_t st) {
-    const int ks0 = a.n_num <= 16 ? 1 : 2;
-    a.n_chunks = chunks_of(4 * ks0 + 136);
-    const double fl = 2.0 * a.B * (256.0 * 128 + 2 * 128.0 * 128 + 2 * 128.0 * a.n_num), by = (double)a.B * (1024 + 128 + 4.0 * a.n_num);
+    a.n_chunks = chunks_of(104);
+    if (!a.mask1 || !a.g3 || a.n_num > 32) {
+        clava_set_error("cls_back: needs the derivative bits cls_front stored, the gradient rows and <= 32 numeric columns");
+        return CLAVA_ERR_ARG;
+    }
+    const double fl = 2.0 * a.B * (256.0 * 128 + 128.0 * 128 + 128.0 * a.n_num), by = (double)a.B * (1024 + 16 + 4.0 * a.n_num);
     if (a.gauss) {
         if (!a.g.eps || a.g.grad != a.gx || a.g.ld_grad != a.ld_gx || a.g.B != a.B || a.g.n_num != a.n_num) {
             clava_set_error("cls_back: the fused Gaussian step must take this launch's gradient and the denoiser's eps");
             return CLAVA_ERR_ARG;
         }
-        return ks0 == 1 ? launch_rows(cls_back_kernel<1, true>, 14, a, a.B, st, "cls_back_gauss", fl, by)
-                        : launch_rows(cls_back_kernel<2, true>, 15, a, a.B, st, "cls_back_gauss", fl, by);
+        return launch_rows(cls_back_kernel<true>, 14, a, a.B, st, "cls_back_gauss", fl, by);
     }
-    return ks0 == 1 ? launch_rows(cls_back_kernel<1, false>, 9, a, a.B, st, "cls_back", fl, by)
-                    : launch_rows(cls_back_kernel<2, false>, 10, a, a.B, st, "cls_back", fl, by);
+    return launch_rows(cls_back_kernel<false>, 9, a, a.B, st, "cls_back", fl, by);
 }
 
 bool clava_den_head_supports(int hidden) { return hidden == 256 || hidden == 512 || hidden == 1024; }

@@ -250,7 +250,7 @@ class SplitNet:
         if narrow_in and need_grad and n == 9 and d[2] == 128 and d[3] == 256 and d[7] == 256 and d[8] == 128 and d[9] <= 64:
             self.fs_front = fused_stream([pk(0), pk(1), pk(2)])
             self.fs_tail = fused_stream([pk(7), pk(8, n_pad=64), pkt(8, k_pad=64), pkt(7)])
-            self.fs_back = fused_stream([pk(0), pk(1), pkt(2), pkt(1), pkt(0)])
+            self.fs_back = fused_stream([pkt(2), pkt(1), pkt(0)])
             for l in (0, 1, 2, 7):
                 self.bf[l] = pad_bias(fb[l])
             self.bf[8] = pad_bias(fb[8], 64)
