@@ -39,6 +39,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static __device__ long long g_stamps[16];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
+// -DCLAVA_BACK_STAMPS (tools/build_variant.py): the stamps come from cls_back instead
+#ifdef CLAVA_BACK_STAMPS
+#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#undef STAMP
+#define STAMP(i)
+#else
+#define BSTAMP(i)
+#endif
 namespace {
 
 constexpr int WAVES_PER_WG = 4;
@@ -498,6 +506,7 @@ __global__ void __launch_bounds__(256) cls_tail_kernel(FusedTailArgs a) {
 // the same thread, as in narrow_split_kernel<.., true>: one launch and one cross-stream hand-over less per step.
 template <bool GAUSS>
 __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
+    BSTAMP(0);
     const Lane L = lane_of(a.B);
     StagedAct<8> in;
     in.issue(a.g3, a.pitch_g3, wave_row0(), a.B);
@@ -510,33 +519,63 @@ __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
         h8 g3h[16], g3l[16];
         in.finish(stage_tile(), g3h, g3l);
         f32x16 acc[4];
+        BSTAMP(1);
         wave_linear<16, 4, 0>(r, g3h, g3l, acc);
+        BSTAMP(2);
         const unsigned bits[2] = {mb[0], mb[1]};
         epi_backward_bits<4>(acc, bits, a.slope1, a.scale_acc_g2);
         to_frags<4>(acc, a.scale_out_g2, g2h, g2l, ovf);
+        BSTAMP(3);
     }
     h8 g1h[8], g1l[8];
     {
         f32x16 acc[4];
         wave_linear<8, 4, P3>(r, g2h, g2l, acc);
+        BSTAMP(4);
         epi_scale<4>(acc, a.scale_acc_g1);                     // proj has no activation
         to_frags<4>(acc, a.scale_out_g1, g1h, g1l, ovf);
+        BSTAMP(5);
     }
     {
         f32x16 acc[1];
         wave_linear<8, 1, P4>(r, g1h, g1l, acc);
+        BSTAMP(6);
         if (L.valid) {
+            if constexpr (GAUSS) {
+                // the step of this lane's elements, four at a time (accumulator registers 4 q .. 4 q + 3 are 4 consecutive
+                // columns): every fetch of a group is in flight before its arithmetic starts
+                const GaussRow k = gauss_row(a.g, (int)L.row);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int c = feat(0, v, L.h);
-                if (c < a.n_num) {
-                    a.gx[L.row * a.ld_gx + c] = acc[0][v] * a.scale_acc_g0;                   // alpha folded into the scale
-                    if constexpr (GAUSS)         // (reads the gradient this thread just stored)
-                        gauss_step_element(a.g, (int)L.row, c, a.g.eps[(size_t)L.row * a.g.ld_eps + c]);
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = feat(0, 4 * q, L.h);
+                    if (c0 < a.n_num) {
+                        GaussIn in4[4];
+                        float e4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (c0 + u < a.n_num) {
+                                e4[u] = a.g.eps[(size_t)L.row * a.g.ld_eps + c0 + u];
+                                in4[u] = gauss_in(a.g, (int)L.row, c0 + u);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (c0 + u < a.n_num) {
+                                const float g = acc[0][4 * q + u] * a.scale_acc_g0;           // alpha folded into the scale
+                                a.gx[L.row * a.ld_gx + c0 + u] = g;
+                                gauss_apply(a.g, k, in4[u], (int)L.row, c0 + u, e4[u], g);
+                            }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int c = feat(0, v, L.h);
+                    if (c < a.n_num) a.gx[L.row * a.ld_gx + c] = acc[0][v] * a.scale_acc_g0;  // alpha folded into the scale
                 }
             }
         }
     }
+    BSTAMP(7);
     if (!(ovf <= 65504.f) && a.overflow) *a.overflow = 1;
 }
 

@@ -90,40 +90,65 @@ __device__ __forceinline__ void store_split(const SplitOut& o, int row, int col,
 // operation and promotion by promotion (float64 chain state, float32 tables, `mean.float()` inside condition_mean).
 // Shared by gauss_step_kernel (diffusion_step.hip) and the fused denoiser-head kernel (fused_narrow.hip).  Files that use
 // it are compiled with -ffp-contract=off so that a*b + c*d rounds like the separate ATen ops do.
-__device__ __forceinline__ void gauss_step_element(const GaussStepArgs& a, int row, int col, float e) {
+// In three pieces so that a caller with several elements per thread can fetch everything first and then do the arithmetic
+// (fused_narrow.hip: cls_back): the row's table entries, the element's inputs, the step itself.  gauss_step_element is the
+// three in a row; the arithmetic is the same statements either way.
+struct GaussRow {              // what depends on the row's t only
+    int t;
+    float sr, srm1, c1, c2;
+    double var, sigma_keep;
+};
+__device__ __forceinline__ GaussRow gauss_row(const GaussStepArgs& a, int row) {
+    GaussRow k;
+    k.t = a.t_rows ? (int)a.t_rows[row] : a.t;
+    k.sr = a.s.sqrt_recip_alphas_cumprod[k.t]; k.srm1 = a.s.sqrt_recipm1_alphas_cumprod[k.t];
+    k.c1 = a.s.posterior_mean_coef1[k.t]; k.c2 = a.s.posterior_mean_coef2[k.t];
+    k.var = a.grad ? a.s.model_variance[k.t] : 0.0;
+    const double keep = (k.t != 0) ? 1.0 : 0.0;            // nonzero_mask (:373-375)
+    k.sigma_keep = keep * a.s.model_sigma[k.t];
+    return k;
+}
+struct GaussIn { double xd, z; };
+__device__ __forceinline__ GaussIn gauss_in(const GaussStepArgs& a, int row, int col) {
     const long long i = (long long)row * a.n_num + col;
-    const int t = a.t_rows ? (int)a.t_rows[row] : a.t;
-    const float sr = a.s.sqrt_recip_alphas_cumprod[t], srm1 = a.s.sqrt_recipm1_alphas_cumprod[t];
-    const float c1 = a.s.posterior_mean_coef1[t], c2 = a.s.posterior_mean_coef2[t];
-    const double xd = a.x[i];
-    double pred, mean;
-    if (a.x_is_f32) {          // first step of a chain: x is the float32 draw, the reference computes in float32 (:1029)
-        const float xf = (float)xd;
-        const float pf = sr * xf - srm1 * e;
-        pred = (double)pf;
-        mean = (double)(c1 * pf + c2 * xf);
-    } else {                   // afterwards x is float64; float32 tables promote, eps * table stays a float32 product (:305-306)
-        pred = (double)sr * xd - (double)(srm1 * e);
-        mean = (double)c1 * pred + (double)c2 * xd;
-    }
-    if (a.grad) {              // condition_mean: mean.float() + variance * gradient.float()  (:325-327)
-        const float g = a.grad[(size_t)row * a.ld_grad + col];
-        mean = (double)(float)mean + a.s.model_variance[t] * (double)g;
-    }
-    double z;
+    GaussIn v;
+    v.xd = a.x[i];
     if (a.noise) {
-        z = a.noise[i];
+        v.z = a.noise[i];
     } else {
         const unsigned long long elem = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.n_num + col;
         const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem, a.step_index, clava_rng::STREAM_GAUSS);
-        z = (double)clava_rng::to_normal(r.x, r.y);
+        v.z = (double)clava_rng::to_normal(r.x, r.y);
     }
-    const double keep = (t != 0) ? 1.0 : 0.0;              // nonzero_mask (:373-375)
-    const double out = mean + (keep * a.s.model_sigma[t]) * z;
+    return v;
+}
+// e = the denoiser's eps, g = the guidance gradient (ignored when a.grad is null)
+__device__ __forceinline__ void gauss_apply(const GaussStepArgs& a, const GaussRow& k, const GaussIn& v, int row, int col, float e, float g) {
+    const long long i = (long long)row * a.n_num + col;
+    const double xd = v.xd;
+    double pred, mean;
+    if (a.x_is_f32) {          // first step of a chain: x is the float32 draw, the reference computes in float32 (:1029)
+        const float xf = (float)xd;
+        const float pf = k.sr * xf - k.srm1 * e;
+        pred = (double)pf;
+        mean = (double)(k.c1 * pf + k.c2 * xf);
+    } else {                   // afterwards x is float64; float32 tables promote, eps * table stays a float32 product (:305-306)
+        pred = (double)k.sr * xd - (double)(k.srm1 * e);
+        mean = (double)k.c1 * pred + (double)k.c2 * xd;
+    }
+    if (a.grad)                // condition_mean: mean.float() + variance * gradient.float()  (:325-327)
+        mean = (double)(float)mean + k.var * (double)g;
+    const double out = mean + k.sigma_keep * v.z;
     a.x[i] = out;
     if (a.pred_xstart) a.pred_xstart[i] = pred;
     if (a.x_in) a.x_in[(size_t)row * a.ld_xin + col] = (float)out;
     if (a.xs.base) store_split(a.xs, row, a.xs.col0 + col, (float)out);
+}
+__device__ __forceinline__ void gauss_step_element(const GaussStepArgs& a, int row, int col, float e) {
+    const GaussRow k = gauss_row(a, row);
+    const GaussIn v = gauss_in(a, row, col);
+    const float g = a.grad ? a.grad[(size_t)row * a.ld_grad + col] : 0.f;
+    gauss_apply(a, k, v, row, col, e, g);
 }
 #endif
 
