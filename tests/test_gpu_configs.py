@@ -391,6 +391,27 @@ def test_fused_narrow_stack_kernels_match_the_per_layer_products(n_num, C, monke
     assert relerr(out["1"], out["0"]) < 2e-6
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_row_groups_on_their_own_streams_change_no_bit(fused, monkeypatch):
+    """CLAVA_CHAIN_GROUPS cuts a batch into row groups that run their steps on separate stream pairs (chain.hip); rows are
+    independent and the noise is keyed by the global row, so the samples are the same bits - with the fused classifier
+    kernels (whose derivative bits live in a per-group slice of the workspace) and layer by layer."""
+    n_num, C, T, b, steps = 2, 50, 1000, 1000 + 13, 4
+    ps, cs, d, clf = _guided_setup(n_num, C, T, 311, 411)
+    cf = make_cond_fn(clf, 1.5)
+    ys = torch.randint(0, C, (b, 1), generator=torch.Generator().manual_seed(5))
+    split_nets.set_gemm_mode("f16x3")
+    n0 = split_nets.fallback_count
+    monkeypatch.setenv("CLAVA_FUSED", fused)
+    out = {}
+    for groups in ("1", "2", "3"):
+        monkeypatch.setenv("CLAVA_CHAIN_GROUPS", groups)
+        out[groups], _ = d.conditional_sample(ys=ys, model_kwargs={"y": ys}, cond_fn=cf, seed=77, n_steps=steps)
+    assert split_nets.fallback_count == n0
+    assert torch.isfinite(out["1"]).all()
+    assert torch.equal(out["1"], out["2"]) and torch.equal(out["1"], out["3"])
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # The END of the chain at config shapes (VERDICT r2 weak 1): t = 4 .. 0 covers the `t-1` clamp of the posterior, the
 # no-noise branch at t = 0, `model_variance[0] = posterior_variance[1]` and a float64 state (every step but the first of a
