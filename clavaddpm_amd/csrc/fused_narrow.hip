@@ -508,10 +508,38 @@ template <bool GAUSS>
 __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
     BSTAMP(0);
     const Lane L = lane_of(a.B);
+    // the Gaussian step's inputs that do not depend on the gradient - table entries, state, eps, the noise - for the lane's
+    // first four columns (all of them up to 8 numeric columns): their loads are the kernel's FIRST (the ring's counted waits
+    // retire memory operations in order: issued later they would hold up a chunk barrier), the Philox draw follows once the
+    // gradient rows and the first weight chunks are on their way
+    GaussRow gk = {};
+    GaussIn gin0[4] = {};
+    float ge0[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool g_lane = GAUSS && L.valid && 4 * L.h < a.n_num;
+    if constexpr (GAUSS) {
+        if (g_lane) {
+            gk = gauss_row(a.g, (int)L.row);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (4 * L.h + u < a.n_num) {
+                    const long long i = (long long)L.row * a.n_num + 4 * L.h + u;
+                    ge0[u] = a.g.eps[(size_t)L.row * a.g.ld_eps + 4 * L.h + u];
+                    gin0[u].xd = a.g.x[i];
+                    if (a.g.noise) gin0[u].z = a.g.noise[i];
+                }
+        }
+    }
     StagedAct<8> in;
     in.issue(a.g3, a.pitch_g3, wave_row0(), a.B);
     const u32x2 mb = *reinterpret_cast<const u32x2*>(a.mask1 + (L.row_ld * 2 + L.h) * 2);
     const WRing r = make_ring(a.stream, a.n_chunks);
+    if constexpr (GAUSS) {
+        if (g_lane && !a.g.noise) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (4 * L.h + u < a.n_num) gin0[u].z = gauss_draw(a.g, (int)L.row, 4 * L.h + u);
+        }
+    }
     float ovf = 0.f;      // largest plane magnitude written: beyond the float16 range raises the caller's overflow flag
     constexpr int P3 = 64, P4 = P3 + 32;
     h8 g2h[8], g2l[8];
@@ -544,7 +572,7 @@ __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
             if constexpr (GAUSS) {
                 // the step of this lane's elements, four at a time (accumulator registers 4 q .. 4 q + 3 are 4 consecutive
                 // columns): every fetch of a group is in flight before its arithmetic starts
-                const GaussRow k = gauss_row(a.g, (int)L.row);
+                const GaussRow k = (a.n_num > 8) ? gauss_row(a.g, (int)L.row) : gk;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c0 = feat(0, 4 * q, L.h);
@@ -554,6 +582,7 @@ __global__ void __launch_bounds__(256) cls_back_kernel(FusedBackArgs a) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
                             if (c0 + u < a.n_num) {
+                                if (q == 0) { e4[u] = ge0[u]; in4[u] = gin0[u]; continue; }     // fetched at the start
                                 e4[u] = a.g.eps[(size_t)L.row * a.g.ld_eps + c0 + u];
                                 in4[u] = gauss_in(a.g, (int)L.row, c0 + u);
                             }

@@ -109,17 +109,17 @@ __device__ __forceinline__ GaussRow gauss_row(const GaussStepArgs& a, int row) {
     return k;
 }
 struct GaussIn { double xd, z; };
+// the element's standard normal when the kernel draws it itself (a.noise == null)
+__device__ __forceinline__ double gauss_draw(const GaussStepArgs& a, int row, int col) {
+    const unsigned long long elem = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.n_num + col;
+    const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem, a.step_index, clava_rng::STREAM_GAUSS);
+    return (double)clava_rng::to_normal(r.x, r.y);
+}
 __device__ __forceinline__ GaussIn gauss_in(const GaussStepArgs& a, int row, int col) {
     const long long i = (long long)row * a.n_num + col;
     GaussIn v;
     v.xd = a.x[i];
-    if (a.noise) {
-        v.z = a.noise[i];
-    } else {
-        const unsigned long long elem = (a.row_offset + (unsigned long long)row) * (unsigned long long)a.n_num + col;
-        const clava_rng::u4 r = clava_rng::philox4x32_10(a.seed, elem, a.step_index, clava_rng::STREAM_GAUSS);
-        v.z = (double)clava_rng::to_normal(r.x, r.y);
-    }
+    v.z = a.noise ? a.noise[i] : gauss_draw(a, row, col);
     return v;
 }
 // e = the denoiser's eps, g = the guidance gradient (ignored when a.grad is null)
