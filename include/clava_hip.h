@@ -335,9 +335,10 @@ typedef struct clava_split_net {
      * [16-deep k-step][row tile of 32][hi, lo][lane][8 halves], element j of lane half h of step s holding column
      * 16 s + 8 (j >> 2) + 4 h + (j & 3), zero padded to whole 32 KB chunks.  Denoiser: fs_front = proj, first hidden block;
      * fs_head = head.  Classifier: fs_front = proj, blocks 1-2; fs_tail = block 7, logits layer, their transposes;
-     * fs_back = proj, block 1 (recomputed mask), transposes of block 2, block 1, proj.  bf[l] = b[l] zero padded to a
-     * multiple of 32 floats (64 for the logits layer), host array of n_layers device pointers.
-     * clavaddpm_amd/split_nets.py::fused_streams builds them. */
+     * fs_back = transposes of block 2, block 1, proj (the derivative of block 1 comes as bits the front kernel stored).
+     * bf[l] = b[l] zero padded to a multiple of 32 floats (64 for the logits layer), host array of n_layers device pointers.
+     * clavaddpm_amd/split_nets.py (SplitNet, pack_fused / fused_stream) builds them; CLAVA_FUSED_PARTS selects which of the
+     * kernels a chain uses (default: the classifier's three). */
     const void* fs_front;
     const void* fs_tail;
     const void* fs_back;
