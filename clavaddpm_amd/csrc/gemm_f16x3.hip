@@ -545,6 +545,13 @@ int pick_cfg(int M, int N, int Kp, bool need_bits = false) {
         const long long tiles = (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((N + kCfgs[c].bn - 1) / kCfgs[c].bn);
         if (tiles <= 256 && (tiles >= 160 || c == 9) && !(kCfgs[c].bn > 64 && N <= kCfgs[c].bn / 2)) return c;
     }
+    // 129-256 outputs over a long contraction at sampling batches: 128 x 96 tiles put two workgroups on every CU in ONE round
+    // (57 KB of LDS each), which the serial-tiles model above prices as two rounds (measured at M = 20000, N = 256, K = 512,
+    // tools/bench_f16x3.py: 21.2 us against 23.8 us on the 128 x 160 tile it picks)
+    if (!(off >> 1 & 1) && N > 128 && N <= 256 && Kp >= 512) {
+        const long long tiles = (long long)((M + kCfgs[1].bm - 1) / kCfgs[1].bm) * ((N + kCfgs[1].bn - 1) / kCfgs[1].bn);
+        if (tiles > 256 && tiles <= 512) best = 1;
+    }
     if (best == 6) {
         const long long tiles = (long long)((M + kCfgs[6].bm - 1) / kCfgs[6].bm) * ((N + kCfgs[6].bn - 1) / kCfgs[6].bn);
         if (tiles <= 256 && Kp <= 256 && !(off >> 8 & 1)) best = 8;
